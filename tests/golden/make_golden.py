@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the REFERENCE
+(/root/reference, read-only) on CPU in the build container.
+
+Run (build container only -- /root/reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Only data is written (inputs, expected outputs); no reference source is copied.
+Weights and inputs come from mmlf_amd.synth (numpy RandomState, stream-frozen), so
+the large full-size cases store outputs only.
+
+Groups:
+  G1  tiny net (chs=8, 2 in-blocks, 3 out-blocks, 16x16, B=3): every tensor, BASE/UPR/DPP,
+      train forward, loss, all parameter grads, BN buffers, params after one Adam step,
+      eval forward.
+  G2  full-size net (defaults), formula weights: train/eval outputs, loss, sampled grads.
+  G4  hci4d.Shift alone and the 70-member Ensamble on a tiny UPR net.
+  G5  losses and dl helpers.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+from mmlf.model.feed_forward import FeedForward as RefFeedForward  # noqa: E402
+from mmlf.model.ensamble import Ensamble as RefEnsamble  # noqa: E402
+from mmlf.model import loss as ref_loss  # noqa: E402
+from mmlf.utils import dl as ref_dl  # noqa: E402
+from mmlf.data.hci4d import Shift as RefShift  # noqa: E402
+
+from mmlf_amd import synth  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+BASE_KW = dict(model_ksize=2, model_in_blocks=3, model_out_blocks=8, model_chs=70,
+               model_views=9, model_cross=False, model_uncert=False, model_unet=False,
+               model_discrete=False, model_no_batchnorm=False,
+               model_batchnorm_momentum=0.1, val_disp_min=-3.5, val_disp_max=3.5)
+TINY_KW = dict(BASE_KW, model_in_blocks=2, model_out_blocks=3, model_chs=8)
+VARIANTS = {
+    'base': {},
+    'upr': {'model_uncert': True},
+    'dpp': {'model_discrete': True},
+}
+
+
+def build_ref(kw, seed):
+    spec = synth.param_spec(**kw)
+    state = synth.synth_state(spec, seed)
+    model = RefFeedForward(**kw)
+    ref_keys = list(model.state_dict().keys())
+    assert ref_keys == [n for n, _, _ in spec], 'param_spec drifted from the reference key set'
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    return model, state
+
+
+def train_mask(mask):
+    # reference train/cli.py:194
+    return torch.from_numpy(mask).int() * ref_loss.create_mask_margin(mask.shape, 11)
+
+
+def loss_for(variant, out, gt, mask, kw):
+    if variant == 'upr':
+        return ref_loss.ImprovedUncertaintyL1Loss()(out, gt, mask, None)
+    if variant == 'dpp':
+        tgt = ref_dl.reg_to_class(gt, kw['val_disp_min'], kw['val_disp_max'], 108)
+        return ref_loss.MaskedCrossEntropy()(out, tgt, mask)
+    return ref_loss.MaskedL1Loss()(out, gt, mask)
+
+
+def out_arrays(out, prefix):
+    return {f'{prefix}{k}': v.detach().numpy() for k, v in out.items() if v is not None}
+
+
+def g1_tiny():
+    for variant, extra in VARIANTS.items():
+        kw = dict(TINY_KW, **extra)
+        B, ps = (2 if variant == 'dpp' else 3), 16
+        model, state = build_ref(kw, seed=11)
+        stacks, gt, mask = synth.synth_inputs(B, ps, seed=5)
+        # margin 11 would leave nothing of a 16x16 patch: use margin 3 for the tiny case
+        m = torch.from_numpy(mask).int() * ref_loss.create_mask_margin(mask.shape, 3)
+        tstacks = [torch.from_numpy(s) for s in stacks]
+        tgt = torch.from_numpy(gt)
+        rec = {}
+        # eval forward with the pristine state
+        model.eval()
+        with torch.no_grad():
+            rec.update(out_arrays(model(*tstacks), 'eval_'))
+        # train forward/backward/Adam
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        opt.zero_grad()
+        out = model(*tstacks)
+        rec.update(out_arrays(out, 'train_'))
+        loss = loss_for(variant, out, tgt, m, kw)
+        loss.backward()
+        rec['loss'] = loss.detach().numpy()
+        for n, p in model.named_parameters():
+            rec[f'grad/{n}'] = p.grad.numpy().copy()
+        opt.step()
+        for n, v in model.state_dict().items():
+            rec[f'post/{n}'] = v.numpy().copy()
+        for n, v in state.items():
+            rec[f'state/{n}'] = v
+        for i, s in enumerate(stacks):
+            rec[f'in{i}'] = s
+        rec['gt'] = gt
+        rec['mask'] = m.numpy()
+        np.savez_compressed(os.path.join(HERE, f'g1_tiny_{variant}.npz'), **rec)
+        print('G1', variant, 'loss', float(loss), 'arrays', len(rec))
+
+
+def sample(a, stride=97):
+    return a.reshape(-1)[::stride].copy()
+
+
+def g2_full():
+    for variant, extra in VARIANTS.items():
+        kw = dict(BASE_KW, **extra)
+        model, state = build_ref(kw, seed=21)
+        rec = {}
+        # eval, B=1
+        stacks, gt, mask = synth.synth_inputs(1, 96, seed=7)
+        model.eval()
+        with torch.no_grad():
+            out = model(*[torch.from_numpy(s) for s in stacks])
+        rec['eval_mean'] = out['mean'].numpy()
+        if variant == 'upr':
+            rec['eval_logvar'] = out['logvar'].numpy()
+            rec['eval_posterior_s'] = out['posterior'].numpy()[:, :, ::8, ::8].copy()
+        if variant == 'dpp':
+            sc = out['scores'].numpy()
+            rec['eval_scores_s'] = sc[:, :, ::8, ::8].copy()
+            rec['eval_argmax'] = sc.argmax(1).astype(np.int16)
+            rec['eval_logvar'] = out['logvar'].numpy()
+            rec['eval_posterior_s'] = out['posterior'].numpy()[:, :, ::8, ::8].copy()
+        # train, B=2 (BASE and UPR: forward + loss + sampled grads + BN buffers)
+        if variant in ('base', 'upr'):
+            stacks, gt, mask = synth.synth_inputs(2, 96, seed=8)
+            m = train_mask(mask)
+            model.train()
+            model.zero_grad()
+            out = model(*[torch.from_numpy(s) for s in stacks])
+            loss = loss_for(variant, out, torch.from_numpy(gt), m, kw)
+            loss.backward()
+            rec['train_mean'] = out['mean'].detach().numpy()
+            if variant == 'upr':
+                rec['train_logvar'] = out['logvar'].detach().numpy()
+            rec['loss'] = loss.detach().numpy()
+            for n, p in model.named_parameters():
+                g = p.grad.numpy()
+                rec[f'grad_s/{n}'] = sample(g) if g.size > 4096 else g.copy()
+            for n, v in model.state_dict().items():
+                if 'running' in n or 'num_batches' in n:
+                    rec[f'post/{n}'] = v.numpy().copy()
+        np.savez_compressed(os.path.join(HERE, f'g2_full_{variant}.npz'), **rec)
+        print('G2', variant, {k: v.shape for k, v in rec.items() if not k.startswith(('grad', 'post'))})
+
+
+def g4_shift_ensamble():
+    rec = {}
+    rs = np.random.RandomState(3)
+    stacks = [rs.uniform(size=(1, 9, 3, 12, 14)).astype(np.float32) for _ in range(4)]
+    for i, s in enumerate(stacks):
+        rec[f'in{i}'] = s
+    for d in (-3.5, -0.3, 0.0, 0.3, 2.5, 1.0):
+        data = tuple(torch.from_numpy(s.copy()) for s in stacks)
+        data = RefShift(float(d))(data)
+        for i in range(4):
+            rec[f'shift_{d}_{i}'] = data[i].numpy()
+    np.savez_compressed(os.path.join(HERE, 'g4_shift.npz'), **rec)
+    print('G4 shift ok')
+
+    kw = dict(TINY_KW, model_uncert=True)
+    model, state = build_ref(kw, seed=31)
+    stacks, _, _ = synth.synth_inputs(1, 24, seed=9)
+    ens = RefEnsamble(model, -3.5, 3.5, 0.1)
+    ens.eval()
+    with torch.no_grad():
+        out = ens(*[torch.from_numpy(s) for s in stacks])
+    rec = {k: v.numpy() for k, v in out.items()}
+    for n, v in state.items():
+        rec[f'state/{n}'] = v
+    for i, s in enumerate(stacks):
+        rec[f'in{i}'] = s
+    np.savez_compressed(os.path.join(HERE, 'g4_ensamble.npz'), **rec)
+    print('G4 ensamble', {k: v.shape for k, v in out.items()})
+
+
+def g5_losses():
+    rs = np.random.RandomState(4)
+    rec = {}
+    B, H, W = 2, 20, 22
+    gt = (7.4 * rs.uniform(size=(B, H, W)) - 3.7).astype(np.float32)
+    gt[0, 0, 0] = -3.5 + 0.5 * 7.0 / 107.0  # exactly between two bins: hits no class
+    gt[0, 0, 1] = 3.5
+    gt[0, 0, 2] = -3.5
+    mean = (gt + rs.normal(scale=0.1, size=gt.shape)).astype(np.float32)
+    logvar = rs.normal(scale=0.5, size=gt.shape).astype(np.float32)
+    scores = rs.normal(scale=2.0, size=(B, 108, H, W)).astype(np.float32)
+    mask = (rs.uniform(size=gt.shape) > 0.3).astype(np.int32)
+    mask_padding = (np.abs(gt) < 3.0).astype(np.int32)
+    rec.update(gt=gt, mean=mean, logvar=logvar, scores=scores, mask=mask,
+               mask_padding=mask_padding)
+    tgt, tmean, tlv, tsc = map(torch.from_numpy, (gt, mean, logvar, scores))
+    tmask, tmp = torch.from_numpy(mask), torch.from_numpy(mask_padding)
+    cls = ref_dl.reg_to_class(tgt, -3.5, 3.5, 108)
+    rec['reg_to_class'] = cls.numpy().astype(np.uint8)
+    rec['class_to_reg'] = ref_dl.class_to_reg(cls, -3.5, 3.5, 108).numpy()
+    out = {'mean': tmean, 'logvar': tlv, 'scores': tsc}
+    rec['l1'] = ref_loss.MaskedL1Loss()(out, tgt, tmask).numpy()
+    rec['mse'] = ref_loss.MaskedMSELoss()(out, tgt, tmask).numpy()
+    rec['badpix'] = ref_loss.MaskedBadPix()(out, tgt, tmask).numpy()
+    rec['upr'] = ref_loss.ImprovedUncertaintyL1Loss()(out, tgt, tmask, None).numpy()
+    rec['upr_padding'] = ref_loss.ImprovedUncertaintyL1Loss()(
+        {'mean': tmean.clone(), 'logvar': tlv.clone()}, tgt, tmask, tmp).numpy()
+    rec['ce'] = ref_loss.MaskedCrossEntropy()(out, cls, tmask).numpy()
+    zero = torch.zeros_like(tmask)
+    rec['l1_zero_mask'] = ref_loss.MaskedL1Loss()(out, tgt, zero).numpy()
+    for mg in (0, 11, 15):
+        rec[f'margin_{mg}'] = ref_loss.create_mask_margin((2, 40, 44), mg).numpy()
+    # gradients of the three training losses w.r.t. the head outputs
+    for name, fn, keys in (('l1', lambda o: ref_loss.MaskedL1Loss()(o, tgt, tmask), ['mean']),
+                           ('upr', lambda o: ref_loss.ImprovedUncertaintyL1Loss()(o, tgt, tmask, None),
+                            ['mean', 'logvar']),
+                           ('ce', lambda o: ref_loss.MaskedCrossEntropy()(o, cls, tmask), ['scores'])):
+        o = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+        fn(o).backward()
+        for k in keys:
+            rec[f'd{name}_d{k}'] = o[k].grad.numpy()
+    # UPR / DPP heads given a raw trunk output
+    m_upr = RefFeedForward(**dict(TINY_KW, model_uncert=True))
+    rec['grid_np'] = np.linspace(-3.5, 3.5, 108)
+    rec['grid_torch'] = torch.linspace(-3.5, 3.5, 108).numpy()
+    from mmlf.model.feed_forward import laplacian
+    post = torch.zeros((B, 108, H, W))
+    post[:, :, :, :] = torch.from_numpy(np.linspace(-3.5, 3.5, 108)).view(1, -1, 1, 1)
+    rec['upr_posterior'] = laplacian(post, tmean, torch.exp(tlv)).numpy()
+    del m_upr
+    np.savez_compressed(os.path.join(HERE, 'g5_losses.npz'), **rec)
+    print('G5 ok', len(rec))
+
+
+if __name__ == '__main__':
+    g1_tiny()
+    g4_shift_ensamble()
+    g5_losses()
+    g2_full()
+    sizes = {f: os.path.getsize(os.path.join(HERE, f)) for f in sorted(os.listdir(HERE))
+             if f.endswith('.npz')}
+    print(sizes)
