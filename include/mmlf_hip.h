@@ -1,0 +1,146 @@
+/*
+ * mmlf_hip.h -- C ABI of libmmlf_hip.so, the MI355X (gfx950) kernels behind the EPI-stack CNN
+ * forward/backward path of titus-leistner/mmlf.
+ *
+ * The reference has no FFI: its hot path reaches arithmetic through stock torch.nn modules.  Each
+ * entry point below therefore names the reference call site whose arithmetic it replaces
+ * (paths relative to the reference repo root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer on the current HIP device; the library owns no memory,
+ *    allocates nothing, never synchronises and launches on the `stream` it is given
+ *    (a hipStream_t passed as void*).  Re-entrant; no global mutable state except the
+ *    thread-local last-error string.
+ *  - return value: 0 = ok, nonzero = error (bad argument or launch failure); the text is
+ *    available from mmlf_last_error() on the calling thread.
+ *
+ * Activation layout ("padded grid"): one image of spatial size H x W lives on a
+ * grid of R = H+2 rows and pitch P = W+2 positions, G = R*P positions per image, NHWC with a
+ * channel stride `cs` (multiple of 4 floats).  A tensor of extent (H, W) is stored at grid offset
+ * (1,1) (position shift P+1) with a zero border; a tensor of extent (H+1, W+1) (the output of the
+ * k=2, pad=1 convolution) is stored at grid offset (0,0).  With this layout every 2x2 convolution,
+ * its data gradient and its weight gradient are 4-tap correlations over the flat position index
+ * q = (b*R + y)*P + x with tap offsets {0, 1, P, P+1}.
+ * Buffers must hold mmlf_grid_alloc_positions(B,H,W) positions; positions outside the stored
+ * extent must be zero (the kernels that write a buffer maintain this; the caller zeroes the
+ * head/tail slack once per allocation).
+ */
+#ifndef MMLF_HIP_H
+#define MMLF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMLF_TILE_POSITIONS 256
+
+const char *mmlf_last_error(void);
+int mmlf_abi_version(void);
+
+/* number of positions a grid buffer must provide for batch B and image extent H x W */
+int64_t mmlf_grid_alloc_positions(int B, int H, int W);
+/* number of floats of a packed filter for K input and N output channels (see mmlf_pack_filter) */
+int64_t mmlf_packed_filter_floats(int K, int N);
+/* floats of workspace mmlf_conv2x2_wgrad needs for (Cin, Cout) */
+int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout);
+
+/* filter variants: the H / I streams run the shared stream net on a transposed / transposed+flipped
+ * image (reference mmlf/model/feed_forward.py:236-256); the same result is obtained on the
+ * un-transformed image with the filter taps permuted. */
+enum { MMLF_VAR_IDENTITY = 0, MMLF_VAR_TRANSPOSE = 1, MMLF_VAR_TRANSPOSE_FLIPH = 2 };
+
+/* OIHW master filter (Cout,Cin,2,2) -> packed K-major MFMA operand.
+ * dgrad = 0: K = Cin, N = Cout (forward).  dgrad = 1: K = Cout, N = Cin, taps reversed (data grad).
+ * replaces: the implicit filter layout transforms inside nn.Conv2d (feed_forward.py:123,125). */
+int mmlf_pack_filter(const float *w_oihw, float *packed, int Cout, int Cin, int variant, int dgrad,
+                     void *stream);
+
+/* 4-tap correlation = nn.Conv2d(k=2) forward (feed_forward.py:123,125) or its data gradient.
+ *   out[q + out_shift][n] = valid(q) ? act(bias[n] + sum_t sum_k in[q + off_t][k] * Wp[t][k][n]) : 0
+ * valid(q): q < B*G and y < vh and x < vw.  relu: fuse nn.ReLU (feed_forward.py:124).
+ * relu_ref (nullable): multiply by (relu_ref[q + out_shift][n] > 0) -- ReLU backward fused into dgrad.
+ * N_store channels are written per position (N_store <= cs_out; pad channels get 0). */
+int mmlf_conv2x2(const float *in, int cs_in, int K, const float *packed, const float *bias, int N,
+                 float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
+                 int B, int H, int W, int relu, const float *relu_ref, int cs_ref, void *stream);
+
+/* Weight + bias gradient of the convolution above (autograd of feed_forward.py:123,125 reached
+ * from train/cli.py:257):  gw[co][ci][tap] (+)= sum_q in[q + off_t][ci] * g[q + g_shift][co],
+ * gb[co] (+)= sum_q g[q + g_shift][co].  g must be zero outside its stored extent.
+ * variant maps taps back to the OIHW master; accumulate != 0 adds into gw/gb (shared stream nets). */
+int mmlf_conv2x2_wgrad(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout,
+                       int g_shift, float *gw_oihw, float *gb, int variant, int accumulate,
+                       float *workspace, int B, int H, int W, void *stream);
+
+/* nn.BatchNorm2d training statistics (feed_forward.py:134): per-channel mean / biased variance of
+ * the extent-(H,W) tensor z (zero border), running-stat update (unbiased var), and the affine
+ * coefficients scale = gamma*invstd, shift = beta - mean*scale.  partial: 2*C*nblocks doubles. */
+int mmlf_bn_stats_train(const float *z, int cs, int C, const float *gamma, const float *beta,
+                        float *running_mean, float *running_var, double momentum, double eps,
+                        float *save_mean, float *save_invstd, float *scale, float *shift,
+                        double *partial, int nblocks, int B, int H, int W, void *stream);
+/* eval-mode coefficients from the running statistics */
+int mmlf_bn_coeffs_eval(const float *gamma, const float *beta, const float *running_mean,
+                        const float *running_var, double eps, float *scale, float *shift, int C,
+                        void *stream);
+/* y[q][c_off + c] = interior(q) ? relu(z[q][c]*scale[c] + shift[c]) : 0   (BN apply + nn.ReLU,
+ * feed_forward.py:134-135; writing a channel slice implements torch.cat, feed_forward.py:266-267) */
+int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *scale, const float *shift,
+                       float *y, int cs_y, int c_off, int C_store, int B, int H, int W, void *stream);
+/* BatchNorm2d + ReLU backward, pass 1: per-channel sums of g and g*zhat with
+ * g = gy * (z*scale+shift > 0); emits dgamma, dbeta (accumulating) and coefficients k[3*C]. */
+int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
+                       const float *scale, const float *shift, const float *gamma,
+                       const float *save_mean, const float *save_invstd,
+                       float *dgamma, float *dbeta, int accumulate, float *coef,
+                       double *partial, int nblocks, int B, int H, int W, void *stream);
+/* pass 2: dz[q][c] = interior(q) ? k1*g - k2 - k3*(z - mean) : 0 */
+int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
+                      const float *scale, const float *shift, const float *save_mean,
+                      const float *coef, float *dz, int cs_dz, int B, int H, int W, void *stream);
+
+/* (B, C, H, W) NCHW  <->  padded-grid NHWC (extent (H,W), grid offset (1,1), zero border, zero pad
+ * channels).  replaces the .view / layout handling of feed_forward.py:226-232 and output[:, 0]. */
+int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int B, int H, int W, void *stream);
+int mmlf_unpack_nchw(const float *grid, int cs, float *nchw, int C, int B, int H, int W, void *stream);
+
+/* UPR head (feed_forward.py:292-302, laplacian :9-12): posterior[b,k,y,x] from output[:,0:2]. */
+int mmlf_head_upr(const float *output_nchw, const float *grid108, float *posterior, int steps,
+                  int B, int H, int W, void *stream);
+/* DPP head (feed_forward.py:276-290, dl.py:160-182). */
+int mmlf_head_dpp(const float *scores_nchw, const float *grid_torch, const float *grid_np,
+                  float *one_hot, float *posterior, float *mean, float *logvar, int steps,
+                  int B, int H, int W, void *stream);
+
+/* Losses (value + gradient w.r.t. the raw out_net output, NCHW), reference mmlf/model/loss.py.
+ * kind 0: MaskedL1Loss (:70-77)  1: ImprovedUncertaintyL1Loss without mask_padding (:264-294)
+ *      2: MaskedCrossEntropy (:146-160) with the target built as reg_to_class(gt) (dl.py:109-131).
+ * scratch: >= 2*nblocks doubles.  loss_out: one float.  grad may be NULL (value only). */
+int mmlf_loss_fwd_bwd(int kind, const float *output_nchw, int oc, const float *gt, const int32_t *mask,
+                      const float *grid_torch, double half_step, float *loss_out, float *grad_nchw,
+                      double *scratch, int nblocks, int B, int H, int W, void *stream);
+
+/* torch.optim.Adam step with default hyper-parameters (train/cli.py:117-118,258) on a flat buffer.
+ * g is multiplied by grad_scale first (1/world_size after the RCCL sum all-reduce). */
+int mmlf_adam_step(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1,
+                   double beta2, double eps, int64_t step, double grad_scale, void *stream);
+
+/* hci4d.Shift on device (mmlf/data/hci4d.py:907-990): sub-pixel circular shear of each view, for S
+ * shift values at once.  in: (views,3,H,W) per stack; out: (S,views,3,H,W) per stack.
+ * tab_s[2*(s*views+k)+{0,1}] = integer shifts (shift0, shift1), tab_w[...] = weights (1-alpha, alpha)
+ * computed on the host exactly as hci4d.py:934-938 (math.modf / copysign on doubles). */
+int mmlf_shift_views(const float *h, const float *v, const float *i, const float *d,
+                     float *oh, float *ov, float *oi, float *od, const int32_t *tab_s, const float *tab_w,
+                     int S, int views, int H, int W, void *stream);
+/* Ensamble reduction (mmlf/model/ensamble.py:78-101): means/logvars (S,B,H,W) ->
+ * mean, logvar (arg-min logvar member), posterior (B,S,H,W) = mean of S Laplacians on grid[S]. */
+int mmlf_ensamble_reduce(const float *means, const float *logvars, const float *grid, float *mean,
+                         float *logvar, float *posterior, int S, int B, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

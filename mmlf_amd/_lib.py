@@ -1,0 +1,80 @@
+"""ctypes binding of libmmlf_hip.so (the C ABI declared in include/mmlf_hip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails, a
+RuntimeError is raised (with the text from ``mmlf_last_error()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmmlf_hip.so')
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_d = ctypes.c_double
+
+# name -> (restype, argtypes); must list every symbol of include/mmlf_hip.h
+SIGNATURES = {
+    'mmlf_last_error': (ctypes.c_char_p, []),
+    'mmlf_abi_version': (_i, []),
+    'mmlf_grid_alloc_positions': (_i64, [_i, _i, _i]),
+    'mmlf_packed_filter_floats': (_i64, [_i, _i]),
+    'mmlf_wgrad_workspace_floats': (_i64, [_i, _i]),
+    'mmlf_pack_filter': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_conv2x2': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    'mmlf_conv2x2_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    'mmlf_bn_stats_train': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_bn_coeffs_eval': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _vp]),
+    'mmlf_bn_apply_relu': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mmlf_bn_bwd_reduce': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_bn_bwd_apply': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_pack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_unpack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_head_upr': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_head_dpp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_loss_fwd_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i64, _d, _vp]),
+    'mmlf_shift_views': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_ensamble_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise if it is absent (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: build it with `python -m mmlf_amd.csrc.build` '
+                '(the HIP path has no CPU fallback)')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().mmlf_last_error().decode()
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; nonzero status -> RuntimeError."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed: {last_error()}')
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,433 @@
+// conv.hip -- fp32 MFMA implicit-GEMM kernels for the k=2 convolutions of the EPI-stack CNN
+// (forward, data gradient, weight+bias gradient) on the padded NHWC grid.  gfx950 only.
+//
+// Arithmetic replaced: nn.Conv2d(k=2, pad 1|0) forward / backward as used by
+// reference mmlf/model/feed_forward.py:123,125 (autograd via mmlf/train/cli.py:257).
+//
+// All three are 4-tap correlations over the flat grid position q with tap offsets
+// {0, 1, P, P+1} (include/mmlf_hip.h).  v_mfma_f32_32x32x2_f32 is an exact f32 fma chain, so
+// results are float32-exact up to summation order.
+#include "common.h"
+#include "../../include/mmlf_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// filter packing: OIHW master -> [chunk][tap][kh][NP][4] with k = 8*chunk + 4*kh + s
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_filter_kernel(const float *__restrict__ w, float *__restrict__ out, int Cout, int Cin,
+                                   int variant, int dgrad, int nchunk, int NP)
+{
+    const long long total = (long long)nchunk * 4 * 2 * NP * 4;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        int s = idx & 3;
+        long long r = idx >> 2;
+        int n = r % NP; r /= NP;
+        int kh = r & 1; r >>= 1;
+        int t = r & 3; r >>= 2;
+        int c = (int)r;
+        int k = 8 * c + 4 * kh + s;
+        int ci, co, tsrc;
+        if (!dgrad) { ci = k; co = n; tsrc = t; }
+        else { co = k; ci = n; tsrc = 3 - t; }
+        float v = 0.f;
+        if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 4 + master_tap(tsrc, variant)];
+        out[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float *in;
+    const float *wp;
+    const float *bias;
+    float *out;
+    const float *ref;
+    long long NQ;
+    int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
+};
+
+// 512 threads = 8 waves; tile = 256 positions x NT*32 output channels; wave w owns positions
+// [32w, 32w+32) x all channels (NT accumulator tiles of 32x32).  K is walked in chunks of 8 input
+// channels x 4 taps, double-buffered in LDS:
+//   A (activations): [seg(2)][kh(2)][260] float4  -- seg 0 = positions Q0.., seg 1 = Q0+P..
+//   B (weights)    : [tap(4)][kh(2)][NP]  float4
+// A lane (i = lane&31, kh = lane>>5) reads ONE float4 = channels 4kh..4kh+3 of its position (A)
+// or of its output channel (B): four K=2 MFMA steps pairing channel s of half 0 with 4+s of half 1.
+template <int NT>
+__global__ __launch_bounds__(512) void conv4tap_kernel(ConvArgs a)
+{
+    constexpr int NP = NT * 32;
+    constexpr int A_F4 = 2 * 2 * 260;
+    constexpr int B_F4 = 4 * 2 * NP;
+    constexpr int BUF_F4 = A_F4 + B_F4;
+    constexpr int NB = (B_F4 + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *lds = reinterpret_cast<float4 *>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const long long Q0 = (long long)blockIdx.x * MMLF_TILE;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    // staging registers
+    float4 ra[3], rb[NB];
+    const int apix = tid & 255, akh = tid >> 8;
+    const float *a0 = a.in + (size_t)(Q0 + apix) * a.cs_in + 4 * akh;
+    const float *a1 = a.in + (size_t)(Q0 + a.P + apix) * a.cs_in + 4 * akh;
+    const float *a2 = a.in + (size_t)(Q0 + ((tid >> 1) & 1) * a.P + 256) * a.cs_in + 4 * (tid & 1);
+
+    const int seg2 = (tid >> 1) & 1, kh2 = tid & 1;
+    const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp);
+
+#define CONV_GLOAD(c)                                                                   \
+    do {                                                                                \
+        ra[0] = *reinterpret_cast<const float4 *>(a0 + 8 * (c));                        \
+        ra[1] = *reinterpret_cast<const float4 *>(a1 + 8 * (c));                        \
+        ra[2] = *reinterpret_cast<const float4 *>(a2 + 8 * (c));                        \
+        _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                \
+            const int idx = tid + 512 * j;                                              \
+            rb[j] = wp4[(size_t)(c) * B_F4 + (idx < B_F4 ? idx : B_F4 - 1)];            \
+        }                                                                               \
+    } while (0)
+#define CONV_LSTORE(buf)                                                                \
+    do {                                                                                \
+        float4 *sb = lds + (buf) * BUF_F4;                                              \
+        sb[(0 * 2 + akh) * 260 + apix] = ra[0];                                         \
+        sb[(1 * 2 + akh) * 260 + apix] = ra[1];                                         \
+        if (tid < 4) sb[(seg2 * 2 + kh2) * 260 + 256] = ra[2];                          \
+        _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                \
+            const int idx = tid + 512 * j;                                              \
+            if (idx < B_F4) sb[A_F4 + idx] = rb[j];                                     \
+        }                                                                               \
+    } while (0)
+
+    CONV_GLOAD(0);
+    CONV_LSTORE(0);
+    __syncthreads();
+
+    for (int c = 0; c < a.nchunk; ++c) {
+        const int buf = c & 1;
+        const int cn = (c + 1 < a.nchunk) ? c + 1 : c;  // last iteration reloads chunk c (discarded)
+        CONV_GLOAD(cn);
+        const float4 *base = lds + buf * BUF_F4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 av = base[((t >> 1) * 2 + kh) * 260 + 32 * w + i + (t & 1)];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 bv = base[A_F4 + (t * 2 + kh) * NP + 32 * nt + i];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nt], 0, 0, 0);
+            }
+        }
+        CONV_LSTORE(buf ^ 1);
+        __syncthreads();
+    }
+#undef CONV_GLOAD
+#undef CONV_LSTORE
+
+    // epilogue: D[row = position][col = channel]; lane holds col i, rows (r&3)+8(r>>2)+4kh
+    unsigned valid = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = (int)Q0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int rem = q % a.G;
+        const int y = rem / a.P, x = rem - y * a.P;
+        if (q < a.NQ && y < a.vh && x < a.vw) valid |= 1u << r;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ch = 32 * nt + i;
+        if (ch >= a.n_store) continue;
+        const float bv = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long q = Q0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh + a.out_shift;
+            float v = acc[nt][r] + bv;
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.ref) v = (a.ref[(size_t)q * a.cs_ref + ch] > 0.f) ? v : 0.f;
+            v = (valid >> r & 1) ? v : 0.f;
+            a.out[(size_t)q * a.cs_out + ch] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight-gradient kernel: dW[t][ci][co] = sum_q in[q + off_t][ci] * g[q + g_shift][co]
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float *in;
+    const float *g;
+    float *part;          // [nsplit][4][CIP][NP]
+    long long NQpad;
+    int cs_in, cin, cs_g, g_shift, P, nsplit, nslice, chunks_per_split, nchunks;
+};
+
+#define WG_KQ 32  // positions per chunk
+
+// 256 threads = 4 waves, wave t = tap t.  Block = (32-channel ci slice, position split).
+// MFMA rows = ci (A operand), cols = co (B operand), K = positions.  The first channel past Cin
+// is staged as 1.0 so that row Cin of tap 0 accumulates the bias gradient for free.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void wgrad4tap_kernel(WgradArgs a)
+{
+    constexpr int NP = NT * 32;
+    constexpr int A_FL = 2 * 33 * 32;      // floats
+    constexpr int NA = 3;                  // 528 float4 / 256 threads
+    constexpr int G_F4 = WG_KQ * NP / 4;   // float4s
+    constexpr int NG = G_F4 / 256;         // == NT
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *As = reinterpret_cast<float *>(smem);
+    float *Gs = As + A_FL;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, t = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.x;
+    const int kk = b >> 3;
+    const int slice = kk % a.nslice;
+    const int split = (kk / a.nslice) * 8 + (b & 7);
+    if (split >= a.nsplit) return;
+    const int ci0 = slice * 32;
+    int c_begin = split * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > a.nchunks) c_end = a.nchunks;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    float4 ra[NA], rg[NG];
+    auto gload = [&](int c) {
+        const long long Qc = (long long)c * WG_KQ;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = tid + 256 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < 528) {
+                const int row = idx >> 3, f = idx & 7;
+                const int seg = row >= 33, pix = row - 33 * seg;
+                const int ch = ci0 + 4 * f;
+                if (ch < a.cs_in)
+                    v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch);
+                if (ch == a.cin) v.x = 1.f;
+                if (ch + 1 == a.cin) v.y = 1.f;
+                if (ch + 2 == a.cin) v.z = 1.f;
+                if (ch + 3 == a.cin) v.w = 1.f;
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx / (NP / 4), f = idx - row * (NP / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * f < a.cs_g)
+                v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + 4 * f);
+            rg[j] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < 528) reinterpret_cast<float4 *>(As)[idx] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NG; ++j) reinterpret_cast<float4 *>(Gs)[tid + 256 * j] = rg[j];
+    };
+
+    if (c_begin < c_end) {
+        gload(c_begin);
+        for (int c = c_begin; c < c_end; ++c) {
+            lstore();
+            __syncthreads();
+            if (c + 1 < c_end) gload(c + 1);
+            const float *ap = As + ((t >> 1) * 33 + (t & 1) + kh) * 32 + i;
+            const float *gp = Gs + kh * NP + i;
+#pragma unroll
+            for (int s = 0; s < WG_KQ / 2; ++s) {
+                const float av = ap[2 * s * 32];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float bv = gp[2 * s * NP + 32 * nt];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nt], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int CIP = a.nslice * 32;
+    float *pp = a.part + ((size_t)(split * 4 + t) * CIP + ci0) * NP;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            pp[(size_t)row * NP + 32 * nt + i] = acc[nt][r];
+        }
+}
+
+// sum the position splits and scatter to the OIHW master gradient (+ bias gradient)
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, float *__restrict__ gb,
+                                    int Cin, int Cout, int CIP, int NP, int nsplit, int variant, int accumulate)
+{
+    const int total = 4 * (Cin + 1) * Cout;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int co = idx % Cout;
+    int r = idx / Cout;
+    const int ci = r % (Cin + 1);
+    const int t = r / (Cin + 1);
+    if (ci == Cin && (t != 0 || gb == nullptr)) return;
+    double s = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[((size_t)(sp * 4 + t) * CIP + ci) * NP + co];
+    if (ci == Cin) {
+        gb[co] = accumulate ? gb[co] + (float)s : (float)s;
+    } else {
+        const size_t o = ((size_t)co * Cin + ci) * 4 + master_tap(t, variant);
+        gw[o] = accumulate ? gw[o] + (float)s : (float)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+static int wgrad_nsplit(int nslice)
+{
+    int n = 512 / nslice;       // two 256-thread blocks per CU on 256 CUs
+    n = n / 8 * 8;
+    if (n < 8) n = 8;
+    return n;
+}
+
+extern "C" int64_t mmlf_packed_filter_floats(int K, int N)
+{
+    const int nt = pick_nt(N);
+    if (nt < 0 || K <= 0) return -1;
+    return (int64_t)((K + 7) / 8) * 4 * 2 * (nt * 32) * 4;
+}
+
+extern "C" int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout)
+{
+    const int nt = pick_nt(Cout);
+    if (nt < 0) return -1;
+    const int nslice = (Cin + 1 + 31) / 32;
+    return (int64_t)wgrad_nsplit(nslice) * 4 * (nslice * 32) * (nt * 32);
+}
+
+extern "C" int mmlf_pack_filter(const float *w, float *packed, int Cout, int Cin, int variant, int dgrad,
+                                void *stream)
+{
+    MMLF_CHECK_ARG(w && packed, "mmlf_pack_filter: null pointer");
+    MMLF_CHECK_ARG(variant >= 0 && variant <= 2, "mmlf_pack_filter: bad variant %d", variant);
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const int nt = pick_nt(N);
+    MMLF_CHECK_ARG(nt > 0, "mmlf_pack_filter: N=%d not supported (max 288)", N);
+    const int nchunk = (K + 7) / 8, NP = nt * 32;
+    const long long total = (long long)nchunk * 32 * NP;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_filter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Cout, Cin,
+                       variant, dgrad, nchunk, NP);
+    return mmlf_launch_status("mmlf_pack_filter");
+}
+
+template <int NT>
+static int launch_conv(const ConvArgs &a, long long ntiles, hipStream_t st)
+{
+    constexpr size_t lds = 2 * (2 * 2 * 260 + 4 * 2 * NT * 32) * sizeof(float4);
+    static bool attr_done = false;  // idempotent; a benign race only repeats the call
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_kernel<NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv4tap_kernel<NT>, dim3((unsigned)ntiles), dim3(512), lds, st, a);
+    return mmlf_launch_status("mmlf_conv2x2");
+}
+
+extern "C" int mmlf_conv2x2(const float *in, int cs_in, int K, const float *packed, const float *bias, int N,
+                            float *out, int cs_out, int N_store, int out_shift, int vh, int vw, int B, int H,
+                            int W, int relu, const float *relu_ref, int cs_ref, void *stream)
+{
+    MMLF_CHECK_ARG(in && packed && out, "mmlf_conv2x2: null pointer");
+    MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0, "mmlf_conv2x2: bad shape B=%d H=%d W=%d", B, H, W);
+    MMLF_CHECK_ARG(cs_in > 0 && cs_in % 8 == 0, "mmlf_conv2x2: cs_in=%d must be a multiple of 8", cs_in);
+    MMLF_CHECK_ARG(K > 0 && (K + 7) / 8 * 8 == cs_in, "mmlf_conv2x2: K=%d does not match cs_in=%d", K, cs_in);
+    const int nt = pick_nt(N);
+    MMLF_CHECK_ARG(nt > 0, "mmlf_conv2x2: N=%d not supported (max 288)", N);
+    MMLF_CHECK_ARG(N_store > 0 && N_store <= cs_out && N_store <= nt * 32,
+                   "mmlf_conv2x2: N_store=%d vs cs_out=%d NP=%d", N_store, cs_out, nt * 32);
+    Grid g = make_grid(B, H, W);
+    MMLF_CHECK_ARG(out_shift >= 0 && out_shift <= g.P + 1, "mmlf_conv2x2: out_shift=%d", out_shift);
+    MMLF_CHECK_ARG(!relu_ref || cs_ref >= N_store, "mmlf_conv2x2: cs_ref=%d < N_store", cs_ref);
+    ConvArgs a;
+    a.in = in; a.wp = packed; a.bias = bias; a.out = out; a.ref = relu_ref;
+    a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
+    a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
+    const long long ntiles = g.NQpad / MMLF_TILE;
+    hipStream_t st = (hipStream_t)stream;
+    switch (nt) {
+    case 1: return launch_conv<1>(a, ntiles, st);
+    case 3: return launch_conv<3>(a, ntiles, st);
+    case 4: return launch_conv<4>(a, ntiles, st);
+    default: return launch_conv<9>(a, ntiles, st);
+    }
+}
+
+template <int NT>
+static int launch_wgrad(const WgradArgs &a, hipStream_t st)
+{
+    constexpr size_t lds = (2 * 33 * 32 + WG_KQ * NT * 32) * sizeof(float);
+    hipLaunchKernelGGL(wgrad4tap_kernel<NT>, dim3((unsigned)(a.nslice * a.nsplit)), dim3(256), lds, st, a);
+    return mmlf_launch_status("mmlf_conv2x2_wgrad");
+}
+
+extern "C" int mmlf_conv2x2_wgrad(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout,
+                                  int g_shift, float *gw, float *gb, int variant, int accumulate,
+                                  float *workspace, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(in && g && gw && workspace, "mmlf_conv2x2_wgrad: null pointer");
+    MMLF_CHECK_ARG(cs_in % 4 == 0 && cs_g % 4 == 0, "mmlf_conv2x2_wgrad: strides must be multiples of 4");
+    MMLF_CHECK_ARG(Cin > 0 && Cin <= cs_in && Cout > 0 && Cout <= cs_g, "mmlf_conv2x2_wgrad: channels vs strides");
+    const int nt = pick_nt(Cout);
+    MMLF_CHECK_ARG(nt > 0, "mmlf_conv2x2_wgrad: Cout=%d not supported", Cout);
+    MMLF_CHECK_ARG(variant >= 0 && variant <= 2, "mmlf_conv2x2_wgrad: bad variant");
+    Grid gr = make_grid(B, H, W);
+    MMLF_CHECK_ARG(g_shift >= 0 && g_shift <= gr.P + 1, "mmlf_conv2x2_wgrad: g_shift=%d", g_shift);
+    WgradArgs a;
+    a.in = in; a.g = g; a.part = workspace; a.NQpad = gr.NQpad;
+    a.cs_in = cs_in; a.cin = Cin; a.cs_g = cs_g; a.g_shift = g_shift; a.P = gr.P;
+    a.nslice = (Cin + 1 + 31) / 32;   // +1: the ones row that yields the bias gradient
+    a.nsplit = wgrad_nsplit(a.nslice);
+    a.nchunks = (int)(gr.NQpad / WG_KQ);
+    a.chunks_per_split = (a.nchunks + a.nsplit - 1) / a.nsplit;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (nt) {
+    case 1: rc = launch_wgrad<1>(a, st); break;
+    case 3: rc = launch_wgrad<3>(a, st); break;
+    case 4: rc = launch_wgrad<4>(a, st); break;
+    default: rc = launch_wgrad<9>(a, st); break;
+    }
+    if (rc) return rc;
+    const int total = 4 * (Cin + 1) * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw, gb, Cin,
+                       Cout, a.nslice * 32, nt * 32, a.nsplit, variant, accumulate);
+    return mmlf_launch_status("mmlf_conv2x2_wgrad(reduce)");
+}

@@ -1,0 +1,707 @@
+// elementwise.hip -- HBM-bound kernels around the convolutions: batch-norm statistics / apply /
+// backward, layout pack/unpack, UPR / DPP heads, losses, Adam, Shift and the ensemble reduce.
+// gfx950 only.  Reference call sites are cited per entry point in include/mmlf_hip.h.
+#include "common.h"
+#include "../../include/mmlf_hip.h"
+
+thread_local char g_mmlf_err[512] = "";
+
+extern "C" const char *mmlf_last_error(void) { return g_mmlf_err; }
+extern "C" int mmlf_abi_version(void) { return 1; }
+extern "C" int64_t mmlf_grid_alloc_positions(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return -1;
+    return grid_alloc_positions(make_grid(B, H, W));
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel reductions over grid rows.  A block walks grid rows r = blockIdx.x, +gridDim.x, ...
+// (border rows are all zero and skipped).  Threads map to (position-in-group, float4 channel
+// group) so that a thread keeps a fixed channel group; double accumulators.
+// ---------------------------------------------------------------------------------------------
+template <int V> struct VecIO;
+template <> struct VecIO<4> {
+    static __device__ __forceinline__ void load(const float *p, float *o)
+    {
+        const float4 v = *reinterpret_cast<const float4 *>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    static __device__ __forceinline__ void store(float *p, const float *o)
+    {
+        *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+};
+template <> struct VecIO<2> {
+    static __device__ __forceinline__ void load(const float *p, float *o)
+    {
+        const float2 v = *reinterpret_cast<const float2 *>(p);
+        o[0] = v.x; o[1] = v.y;
+    }
+    static __device__ __forceinline__ void store(float *p, const float *o)
+    {
+        *reinterpret_cast<float2 *>(p) = make_float2(o[0], o[1]);
+    }
+};
+
+// V = channels per thread access (4 when every slice start is 16-byte aligned, else 2: the
+// 70-channel stream slices of the 280-channel concat buffer start at 280-byte multiples).
+template <bool BWD, int V>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ z, int cs_z,
+                                                        const float *__restrict__ gy, int cs_gy, int c_off,
+                                                        const float *__restrict__ scale,
+                                                        const float *__restrict__ shift,
+                                                        const float *__restrict__ mean,
+                                                        const float *__restrict__ invstd, int C,
+                                                        double *__restrict__ partial, int B, int H, int W)
+{
+    const int P = W + 2, R = H + 2;
+    const int cvn = (C + V - 1) / V;            // channel groups that hold real channels
+    const int ppi = 256 / cvn;                  // positions per iteration
+    const int tid = threadIdx.x;
+    const int pl = tid / cvn, cg = tid - pl * cvn;
+    const bool active = pl < ppi;
+    double s0[V], s1[V];
+    float sc[V], sh[V], mu[V], iv[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s0[e] = 0; s1[e] = 0; sc[e] = sh[e] = mu[e] = iv[e] = 0.f; }
+    if (BWD && active) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int c = V * cg + e;
+            if (c < C) { sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; iv[e] = invstd[c]; }
+        }
+    }
+    const int nrows = B * H;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int b = row / H, y = row - b * H + 1;
+        const size_t base = ((size_t)(b * R + y) * P + 1);  // first interior position of the row
+        for (int x = pl; active && x < W; x += ppi) {
+            float zz[V];
+            VecIO<V>::load(z + (base + x) * cs_z + V * cg, zz);
+            if (!BWD) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) { s0[e] += zz[e]; s1[e] += (double)zz[e] * zz[e]; }
+            } else {
+                float gg[V];
+                VecIO<V>::load(gy + (base + x) * cs_gy + c_off + V * cg, gg);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float u = fmaf(zz[e], sc[e], sh[e]);
+                    const float g = u > 0.f ? gg[e] : 0.f;
+                    s0[e] += g;
+                    s1[e] += (double)g * (double)((zz[e] - mu[e]) * iv[e]);
+                }
+            }
+        }
+    }
+    __shared__ double red[2][256][V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { red[0][tid][e] = s0[e]; red[1][tid][e] = s1[e]; }
+    __syncthreads();
+    if (tid < cvn) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            double a0 = 0, a1 = 0;
+            for (int p = 0; p < ppi; ++p) { a0 += red[0][p * cvn + tid][e]; a1 += red[1][p * cvn + tid][e]; }
+            const int c = V * tid + e;
+            if (c < C) {
+                partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a0;
+                partial[((size_t)blockIdx.x * 2 + 1) * C + c] = a1;
+            }
+        }
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const double *__restrict__ partial, int nblocks, int C, double n,
+                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                         float *running_mean, float *running_var, double momentum, double eps,
+                                         float *save_mean, float *save_invstd, float *scale, float *shift)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, ss = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        s += partial[((size_t)b * 2 + 0) * C + c];
+        ss += partial[((size_t)b * 2 + 1) * C + c];
+    }
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0) var = 0;
+    const double invstd = 1.0 / sqrt(var + eps);
+    const float meanf = (float)mean, invf = (float)invstd;
+    save_mean[c] = meanf;
+    save_invstd[c] = invf;
+    if (running_mean) {
+        const double unb = n > 1 ? var * n / (n - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+    const float sc = (gamma ? gamma[c] : 1.f) * invf;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - meanf * sc;
+}
+
+__global__ void bn_coeffs_eval_kernel(const float *gamma, const float *beta, const float *rm, const float *rv,
+                                      double eps, float *scale, float *shift, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invf = (float)(1.0 / sqrt((double)rv[c] + eps));
+    const float sc = (gamma ? gamma[c] : 1.f) * invf;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblocks, int C, double n,
+                                       const float *__restrict__ gamma, const float *__restrict__ invstd,
+                                       float *dgamma, float *dbeta, int accumulate, float *coef)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sg = 0, sgx = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        sg += partial[((size_t)b * 2 + 0) * C + c];
+        sgx += partial[((size_t)b * 2 + 1) * C + c];
+    }
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
+    const double k1 = (double)(gamma ? gamma[c] : 1.f) * invstd[c];
+    coef[c] = (float)k1;
+    coef[C + c] = (float)(k1 * sg / n);
+    coef[2 * C + c] = (float)(k1 * (double)invstd[c] * sgx / n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-wise elementwise kernels: one block per grid row (b, y), y in [0, R)
+// MODE 0: y = relu(z*scale+shift) (interior) | MODE 1: dz = k1*g - k2 - k3*(z-mean), g = gy*(u>0)
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int V>
+__global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ z, int cs_z,
+                                                      const float *__restrict__ gy, int cs_gy, int c_off_gy,
+                                                      const float *__restrict__ scale,
+                                                      const float *__restrict__ shift,
+                                                      const float *__restrict__ mean,
+                                                      const float *__restrict__ coef, int C,
+                                                      float *__restrict__ out, int cs_out, int c_off_out,
+                                                      int C_store, int H, int W)
+{
+    const int P = W + 2, R = H + 2;
+    const int row = blockIdx.x;
+    const int y = row % R;
+    const size_t base = (size_t)row * P;
+    const int cvn = (C_store + V - 1) / V;
+    const bool row_in = (y >= 1 && y <= H);
+    const int total = P * cvn;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int x = e / cvn, cg = e - x * cvn;
+        float o[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = 0.f;
+        if (row_in && x >= 1 && x <= W && V * cg < C) {
+            float zz[V], gg[V];
+            VecIO<V>::load(z + (base + x) * cs_z + V * cg, zz);
+            if (MODE == 1) VecIO<V>::load(gy + (base + x) * cs_gy + c_off_gy + V * cg, gg);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int c = V * cg + k;
+                if (c < C) {
+                    const float u = fmaf(zz[k], scale[c], shift[c]);
+                    if (MODE == 0) {
+                        o[k] = fmaxf(u, 0.f);
+                    } else {
+                        const float g = u > 0.f ? gg[k] : 0.f;
+                        o[k] = coef[c] * g - coef[C + c] - coef[2 * C + c] * (zz[k] - mean[c]);
+                    }
+                }
+            }
+        }
+        float *op = out + (base + x) * cs_out + c_off_out + V * cg;
+        if (V * cg + V - 1 < C_store) {
+            VecIO<V>::store(op, o);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                if (V * cg + k < C_store) op[k] = o[k];
+        }
+    }
+}
+
+// NCHW <-> grid
+__global__ __launch_bounds__(256) void pack_nchw_kernel(const float *__restrict__ src, int C,
+                                                        float *__restrict__ grid, int cs, int H, int W)
+{
+    const int P = W + 2, R = H + 2;
+    const int row = blockIdx.x;
+    const int b = row / R, y = row - b * R;
+    const size_t base = (size_t)row * P;
+    const int c4n = cs / 4;
+    const bool row_in = (y >= 1 && y <= H);
+    const int total = P * c4n;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int cg = e / P, x = e - cg * P;  // x fastest: coalesced NCHW reads
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row_in && x >= 1 && x <= W) {
+            for (int k = 0; k < 4; ++k) {
+                const int c = 4 * cg + k;
+                if (c < C) o[k] = src[(((size_t)b * C + c) * H + (y - 1)) * W + (x - 1)];
+            }
+        }
+        *reinterpret_cast<float4 *>(grid + (base + x) * cs + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_nchw_kernel(const float *__restrict__ grid, int cs,
+                                                          float *__restrict__ dst, int C, int H, int W)
+{
+    const int P = W + 2, R = H + 2;
+    const int row = blockIdx.x;  // b*H + (y-1)
+    const int b = row / H, y = row - b * H + 1;
+    const size_t base = ((size_t)(b * R + y)) * P;
+    const int total = W * C;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int c = e / W, x = e - c * W;
+        dst[(((size_t)b * C + c) * H + (y - 1)) * W + x] = grid[(base + x + 1) * cs + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// heads
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float laplace_pdf(float x, float mu, float b)
+{
+    // 1.0 / (2.0 * b) * exp(-|x - mu| / b), reference feed_forward.py:9-12 (float32 op order)
+    const float a = __fdiv_rn(1.0f, __fmul_rn(2.0f, b));
+    const float t = __fdiv_rn(-fabsf(__fsub_rn(x, mu)), b);
+    return __fmul_rn(a, expf(t));
+}
+
+__global__ void head_upr_kernel(const float *__restrict__ out, const float *__restrict__ grid,
+                                float *__restrict__ post, int steps, int HW, long long total)
+{
+    // out: (B,2,H,W); post: (B,steps,H,W)
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / HW;
+        const int p = (int)(idx - b * HW);
+        const float mu = out[(b * 2 + 0) * HW + p];
+        const float bb = expf(out[(b * 2 + 1) * HW + p]);
+        for (int k = 0; k < steps; ++k) post[(b * steps + k) * HW + p] = laplace_pdf(grid[k], mu, bb);
+    }
+}
+
+__global__ void head_dpp_kernel(const float *__restrict__ sc, const float *__restrict__ gt, const float *__restrict__ gn,
+                                float *__restrict__ one_hot, float *__restrict__ post, float *__restrict__ mean,
+                                float *__restrict__ logvar, int steps, int HW, long long total)
+{
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / HW;
+        const int p = (int)(idx - b * HW);
+        const float *s = sc + b * steps * HW + p;
+        float mx = -INFINITY, z = 0.f;
+        for (int k = 0; k < steps; ++k) {
+            const float v = s[(size_t)k * HW];
+            mx = fmaxf(mx, v);
+            z = __fadd_rn(z, expf(v));
+        }
+        float m = 0.f;
+        for (int k = 0; k < steps; ++k) {
+            const float v = s[(size_t)k * HW];
+            const float oh = (v == mx) ? 1.f : 0.f;
+            one_hot[(b * steps + k) * HW + p] = oh;
+            m = __fadd_rn(m, __fmul_rn(gt[k], oh));
+        }
+        float lv = 0.f;
+        for (int k = 0; k < steps; ++k) {
+            const float v = s[(size_t)k * HW];
+            const float pk = __fdiv_rn(expf(v), z);
+            post[(b * steps + k) * HW + p] = pk;
+            const float d = __fsub_rn(gn[k], m);
+            lv = __fadd_rn(lv, __fmul_rn(__fmul_rn(d, d), pk));
+        }
+        mean[idx] = m;
+        logvar[idx] = logf(lv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// losses: pass 1 partial (count, sum), finalize, pass 2 gradient
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgnf(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+
+__device__ __forceinline__ float ce_pixel(const float *s, int steps, int HW, float gtv, const float *grid,
+                                          float half_step, float *z_out)
+{
+    float dot = 0.f, z = 0.f;
+    for (int k = 0; k < steps; ++k) {
+        const float v = fmaxf(s[(size_t)k * HW], 0.f);
+        const float t = fabsf(__fsub_rn(grid[k], gtv)) < half_step ? 1.f : 0.f;
+        dot = __fadd_rn(dot, __fmul_rn(v, t));
+        z = __fadd_rn(z, expf(v));
+    }
+    *z_out = z;
+    return -logf(__fdiv_rn(expf(dot), z));
+}
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(int kind, const float *__restrict__ out, int oc,
+                                                           const float *__restrict__ gt,
+                                                           const int32_t *__restrict__ mask,
+                                                           const float *__restrict__ grid, float half_step,
+                                                           double *__restrict__ scratch, int HW, long long total)
+{
+    double cnt = 0, sum = 0;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / HW;
+        const int p = (int)(idx - b * HW);
+        const int mk = mask[idx];
+        cnt += mk;
+        float l;
+        if (kind == 0) {
+            l = fabsf(out[(b * oc) * HW + p] - gt[idx]);
+        } else if (kind == 1) {
+            const float lv = out[(b * oc + 1) * HW + p];
+            l = __fadd_rn(__fmul_rn(expf(-lv), fabsf(out[(b * oc) * HW + p] - gt[idx])), lv);
+        } else {
+            float z;
+            l = ce_pixel(out + b * oc * HW + p, oc, HW, gt[idx], grid, half_step, &z);
+        }
+        sum += (double)(l * (float)mk);
+    }
+    __shared__ double r0[256], r1[256];
+    r0[threadIdx.x] = cnt; r1[threadIdx.x] = sum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { scratch[2 + 2 * blockIdx.x] = r0[0]; scratch[3 + 2 * blockIdx.x] = r1[0]; }
+}
+
+__global__ void loss_finalize_kernel(double *scratch, int nblocks, float *loss_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double cnt = 0, sum = 0;
+    for (int b = 0; b < nblocks; ++b) { cnt += scratch[2 + 2 * b]; sum += scratch[3 + 2 * b]; }
+    const double den = cnt == 0 ? 1.0 : cnt;
+    scratch[0] = 1.0 / den;
+    scratch[1] = cnt;
+    *loss_out = (float)(sum / den);
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(int kind, const float *__restrict__ out, int oc,
+                                                        const float *__restrict__ gt,
+                                                        const int32_t *__restrict__ mask,
+                                                        const float *__restrict__ grid, float half_step,
+                                                        const double *__restrict__ scratch,
+                                                        float *__restrict__ grad, int HW, long long total)
+{
+    const float inv = (float)scratch[0];
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / HW;
+        const int p = (int)(idx - b * HW);
+        const float mk = (float)mask[idx] * inv;
+        if (kind == 0) {
+            grad[(b * oc) * HW + p] = sgnf(out[(b * oc) * HW + p] - gt[idx]) * mk;
+        } else if (kind == 1) {
+            const float d = out[(b * oc) * HW + p] - gt[idx];
+            const float e = expf(-out[(b * oc + 1) * HW + p]);
+            grad[(b * oc) * HW + p] = e * sgnf(d) * mk;
+            grad[(b * oc + 1) * HW + p] = (1.f - e * fabsf(d)) * mk;
+        } else {
+            const float *s = out + b * oc * HW + p;
+            float z;
+            ce_pixel(s, oc, HW, gt[idx], grid, half_step, &z);
+            for (int k = 0; k < oc; ++k) {
+                const float raw = s[(size_t)k * HW];
+                const float t = fabsf(__fsub_rn(grid[k], gt[idx])) < half_step ? 1.f : 0.f;
+                const float g = raw > 0.f ? (expf(raw) / z - t) * mk : 0.f;
+                grad[(b * oc + k) * HW + p] = g;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults: no weight decay, no amsgrad)
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, long long n, float step_size, float beta1, float beta2,
+                            float eps, float bc2_sqrt, float grad_scale)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+        const float vi = v[i] * beta2 + gi * gi * (1.f - beta2);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shift (hci4d.py:907-990) for S shift values at once; in: (views,3,H,W) -> out: (S,views,3,H,W)
+// ---------------------------------------------------------------------------------------------
+struct ShiftTab { int s0, s1; float w0, w1; };
+
+__device__ __forceinline__ int wrapi(int a, int n) { a %= n; return a < 0 ? a + n : a; }
+// source index of a roll by +s with Python-slice clamping (|s| >= n -> identity)
+__device__ __forceinline__ int roll_src(int x, int s, int n) { return (s >= n || -s >= n) ? x : wrapi(x - s, n); }
+
+__global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ h, const float *__restrict__ v,
+                                                    const float *__restrict__ i_, const float *__restrict__ d,
+                                                    float *__restrict__ oh, float *__restrict__ ov,
+                                                    float *__restrict__ oi, float *__restrict__ od,
+                                                    const int32_t *__restrict__ tab_s,
+                                                    const float *__restrict__ tab_w, int views, int H, int W)
+{
+    // grid: (S*views*3*H) rows, threads over x
+    const int row = blockIdx.x;
+    const int y = row % H;
+    int r = row / H;
+    const int ch = r % 3; r /= 3;
+    const int view = r % views;
+    const int s = r / views;
+    ShiftTab t;
+    t.s0 = tab_s[2 * (s * views + view)]; t.s1 = tab_s[2 * (s * views + view) + 1];
+    t.w0 = tab_w[2 * (s * views + view)]; t.w1 = tab_w[2 * (s * views + view) + 1];
+    const float *ph = h + ((size_t)(view * 3 + ch) * H) * W;
+    const float *pv = v + ((size_t)(view * 3 + ch) * H) * W;
+    const float *pi = i_ + ((size_t)(view * 3 + ch) * H) * W;
+    const float *pd = d + ((size_t)(view * 3 + ch) * H) * W;
+    const size_t ob = ((size_t)((s * views + view) * 3 + ch) * H + y) * W;
+    auto lerp = [&](float a, float b) { return __fadd_rn(__fmul_rn(a, t.w0), __fmul_rn(b, t.w1)); };
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        const int x0 = roll_src(x, t.s0, W), x1 = roll_src(x, t.s1, W);
+        // h: along W
+        oh[ob + x] = lerp(ph[(size_t)y * W + x0], ph[(size_t)y * W + x1]);
+        // v: along H
+        const int y0 = roll_src(y, t.s0, H), y1 = roll_src(y, t.s1, H);
+        ov[ob + x] = lerp(pv[(size_t)y0 * W + x], pv[(size_t)y1 * W + x]);
+        // d: W pass then H pass (+s)
+        {
+            const float ta = lerp(pd[(size_t)y0 * W + x0], pd[(size_t)y0 * W + x1]);
+            const float tb = lerp(pd[(size_t)y1 * W + x0], pd[(size_t)y1 * W + x1]);
+            od[ob + x] = lerp(ta, tb);
+        }
+        // i: W pass then H pass with the NEGATED shift (hci4d.py:971-975)
+        {
+            const int yi0 = roll_src(y, -t.s0, H), yi1 = roll_src(y, -t.s1, H);
+            const float ta = lerp(pi[(size_t)yi0 * W + x0], pi[(size_t)yi0 * W + x1]);
+            const float tb = lerp(pi[(size_t)yi1 * W + x0], pi[(size_t)yi1 * W + x1]);
+            oi[ob + x] = lerp(ta, tb);
+        }
+    }
+}
+
+// Ensamble reduce (ensamble.py:78-101)
+__global__ void ensamble_reduce_kernel(const float *__restrict__ means, const float *__restrict__ logvars,
+                                       const float *__restrict__ grid, float *__restrict__ mean,
+                                       float *__restrict__ logvar, float *__restrict__ post, int S, int HW,
+                                       long long total /* B*HW */)
+{
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / HW;
+        const int p = (int)(idx - b * HW);
+        float best = INFINITY;
+        int bi = 0;
+        for (int j = 0; j < S; ++j) {
+            const float lv = logvars[(size_t)j * total + idx];
+            if (lv < best) { best = lv; bi = j; }
+        }
+        mean[idx] = means[(size_t)bi * total + idx];
+        logvar[idx] = best;
+        for (int k = 0; k < S; ++k) {
+            const float gk = grid[k];
+            float acc = 0.f;
+            for (int j = 0; j < S; ++j)
+                acc = __fadd_rn(acc, laplace_pdf(gk, means[(size_t)j * total + idx],
+                                                 expf(logvars[(size_t)j * total + idx])));
+            post[(b * S + k) * HW + p] = __fdiv_rn(acc, (float)S);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI wrappers
+// ---------------------------------------------------------------------------------------------
+static int ew_blocks(long long total, int per = 256)
+{
+    long long b = (total + per - 1) / per;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int mmlf_bn_stats_train(const float *z, int cs, int C, const float *gamma, const float *beta,
+                                   float *running_mean, float *running_var, double momentum, double eps,
+                                   float *save_mean, float *save_invstd, float *scale, float *shift,
+                                   double *partial, int nblocks, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(z && save_mean && save_invstd && scale && shift && partial, "mmlf_bn_stats_train: null pointer");
+    MMLF_CHECK_ARG(cs % 4 == 0 && C > 0 && C <= cs && (C + 3) / 4 <= 256, "mmlf_bn_stats_train: C=%d cs=%d", C, cs);
+    MMLF_CHECK_ARG(nblocks > 0 && nblocks <= 4096, "mmlf_bn_stats_train: nblocks=%d", nblocks);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((bn_reduce_kernel<false, 4>), dim3(nblocks), dim3(256), 0, st, z, cs, nullptr, 0, 0, nullptr,
+                       nullptr, nullptr, nullptr, C, partial, B, H, W);
+    const double n = (double)B * H * W;
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblocks, C, n, gamma,
+                       beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+    return mmlf_launch_status("mmlf_bn_stats_train");
+}
+
+extern "C" int mmlf_bn_coeffs_eval(const float *gamma, const float *beta, const float *rm, const float *rv,
+                                   double eps, float *scale, float *shift, int C, void *stream)
+{
+    MMLF_CHECK_ARG(rm && rv && scale && shift && C > 0, "mmlf_bn_coeffs_eval: bad argument");
+    hipLaunchKernelGGL(bn_coeffs_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta, rm,
+                       rv, eps, scale, shift, C);
+    return mmlf_launch_status("mmlf_bn_coeffs_eval");
+}
+
+extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *scale, const float *shift, float *y,
+                                  int cs_y, int c_off, int C_store, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(z && scale && shift && y, "mmlf_bn_apply_relu: null pointer");
+    MMLF_CHECK_ARG(cs_z % 4 == 0 && cs_y % 2 == 0 && c_off % 2 == 0 && C <= cs_z && C_store >= C &&
+                       c_off + C_store <= cs_y,
+                   "mmlf_bn_apply_relu: C=%d cs_z=%d cs_y=%d c_off=%d C_store=%d", C, cs_z, cs_y, c_off, C_store);
+    if (cs_y % 4 == 0 && c_off % 4 == 0)
+        hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, z, cs_z,
+                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W);
+    else
+        hipLaunchKernelGGL((bn_rows_kernel<0, 2>), dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, z, cs_z,
+                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W);
+    return mmlf_launch_status("mmlf_bn_apply_relu");
+}
+
+extern "C" int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
+                                  const float *scale, const float *shift, const float *gamma,
+                                  const float *save_mean, const float *save_invstd, float *dgamma, float *dbeta,
+                                  int accumulate, float *coef, double *partial, int nblocks, int B, int H, int W,
+                                  void *stream)
+{
+    MMLF_CHECK_ARG(gy && z && scale && shift && save_mean && save_invstd && coef && partial,
+                   "mmlf_bn_bwd_reduce: null pointer");
+    MMLF_CHECK_ARG(cs_gy % 2 == 0 && c_off % 2 == 0 && cs_z % 4 == 0 && C <= cs_z && (C + 1) / 2 <= 256,
+                   "mmlf_bn_bwd_reduce: layout");
+    MMLF_CHECK_ARG(nblocks > 0 && nblocks <= 4096, "mmlf_bn_bwd_reduce: nblocks=%d", nblocks);
+    hipStream_t st = (hipStream_t)stream;
+    if (cs_gy % 4 == 0 && c_off % 4 == 0)
+        hipLaunchKernelGGL((bn_reduce_kernel<true, 4>), dim3(nblocks), dim3(256), 0, st, z, cs_z, gy, cs_gy, c_off,
+                           scale, shift, save_mean, save_invstd, C, partial, B, H, W);
+    else
+        hipLaunchKernelGGL((bn_reduce_kernel<true, 2>), dim3(nblocks), dim3(256), 0, st, z, cs_z, gy, cs_gy, c_off,
+                           scale, shift, save_mean, save_invstd, C, partial, B, H, W);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblocks, C,
+                       (double)B * H * W, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
+    return mmlf_launch_status("mmlf_bn_bwd_reduce");
+}
+
+extern "C" int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
+                                 const float *scale, const float *shift, const float *save_mean, const float *coef,
+                                 float *dz, int cs_dz, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(gy && z && scale && shift && save_mean && coef && dz, "mmlf_bn_bwd_apply: null pointer");
+    MMLF_CHECK_ARG(cs_gy % 2 == 0 && c_off % 2 == 0 && cs_z % 4 == 0 && cs_dz % 4 == 0 && C <= cs_dz,
+                   "mmlf_bn_bwd_apply: layout");
+    if (cs_gy % 4 == 0 && c_off % 4 == 0)
+        hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, z, cs_z, gy,
+                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W);
+    else
+        hipLaunchKernelGGL((bn_rows_kernel<1, 2>), dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, z, cs_z, gy,
+                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W);
+    return mmlf_launch_status("mmlf_bn_bwd_apply");
+}
+
+extern "C" int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(nchw && grid && C > 0 && cs % 4 == 0 && C <= cs, "mmlf_pack_nchw: C=%d cs=%d", C, cs);
+    hipLaunchKernelGGL(pack_nchw_kernel, dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, nchw, C, grid, cs, H, W);
+    return mmlf_launch_status("mmlf_pack_nchw");
+}
+
+extern "C" int mmlf_unpack_nchw(const float *grid, int cs, float *nchw, int C, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(nchw && grid && C > 0 && C <= cs, "mmlf_unpack_nchw: C=%d cs=%d", C, cs);
+    hipLaunchKernelGGL(unpack_nchw_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, grid, cs, nchw, C, H, W);
+    return mmlf_launch_status("mmlf_unpack_nchw");
+}
+
+extern "C" int mmlf_head_upr(const float *output, const float *grid108, float *posterior, int steps, int B, int H,
+                             int W, void *stream)
+{
+    MMLF_CHECK_ARG(output && grid108 && posterior && steps > 0, "mmlf_head_upr: bad argument");
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(head_upr_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, output, grid108,
+                       posterior, steps, H * W, total);
+    return mmlf_launch_status("mmlf_head_upr");
+}
+
+extern "C" int mmlf_head_dpp(const float *scores, const float *grid_torch, const float *grid_np, float *one_hot,
+                             float *posterior, float *mean, float *logvar, int steps, int B, int H, int W,
+                             void *stream)
+{
+    MMLF_CHECK_ARG(scores && grid_torch && grid_np && one_hot && posterior && mean && logvar && steps > 0,
+                   "mmlf_head_dpp: bad argument");
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(head_dpp_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, scores, grid_torch,
+                       grid_np, one_hot, posterior, mean, logvar, steps, H * W, total);
+    return mmlf_launch_status("mmlf_head_dpp");
+}
+
+extern "C" int mmlf_loss_fwd_bwd(int kind, const float *output, int oc, const float *gt, const int32_t *mask,
+                                 const float *grid_torch, double half_step, float *loss_out, float *grad,
+                                 double *scratch, int nblocks, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(kind >= 0 && kind <= 2, "mmlf_loss_fwd_bwd: kind=%d", kind);
+    MMLF_CHECK_ARG(output && gt && mask && loss_out && scratch, "mmlf_loss_fwd_bwd: null pointer");
+    MMLF_CHECK_ARG((kind == 0 && oc >= 1) || (kind == 1 && oc >= 2) || (kind == 2 && grid_torch && oc >= 1),
+                   "mmlf_loss_fwd_bwd: oc=%d for kind=%d", oc, kind);
+    MMLF_CHECK_ARG(nblocks > 0 && nblocks <= 4096, "mmlf_loss_fwd_bwd: nblocks=%d", nblocks);
+    const long long total = (long long)B * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(nblocks), dim3(256), 0, st, kind, output, oc, gt, mask, grid_torch,
+                       (float)half_step, scratch, H * W, total);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, scratch, nblocks, loss_out);
+    if (grad)
+        hipLaunchKernelGGL(loss_grad_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, kind, output, oc, gt, mask,
+                           grid_torch, (float)half_step, scratch, grad, H * W, total);
+    return mmlf_launch_status("mmlf_loss_fwd_bwd");
+}
+
+extern "C" int mmlf_adam_step(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1,
+                              double beta2, double eps, int64_t step, double grad_scale, void *stream)
+{
+    MMLF_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "mmlf_adam_step: bad argument");
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+                       (float)(lr / bc1), (float)beta1, (float)beta2, (float)eps, (float)sqrt(bc2), (float)grad_scale);
+    return mmlf_launch_status("mmlf_adam_step");
+}
+
+extern "C" int mmlf_shift_views(const float *h, const float *v, const float *i, const float *d, float *oh, float *ov,
+                                float *oi, float *od, const int32_t *tab_s, const float *tab_w, int S, int views,
+                                int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(h && v && i && d && oh && ov && oi && od && tab_s && tab_w, "mmlf_shift_views: null pointer");
+    MMLF_CHECK_ARG(S > 0 && views > 0 && H > 0 && W > 0, "mmlf_shift_views: S=%d views=%d", S, views);
+    hipLaunchKernelGGL(shift_kernel, dim3(S * views * 3 * H), dim3(256), 0, (hipStream_t)stream, h, v, i, d, oh, ov,
+                       oi, od, tab_s, tab_w, views, H, W);
+    return mmlf_launch_status("mmlf_shift_views");
+}
+
+extern "C" int mmlf_ensamble_reduce(const float *means, const float *logvars, const float *grid, float *mean,
+                                    float *logvar, float *posterior, int S, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(means && logvars && grid && mean && logvar && posterior && S > 0, "mmlf_ensamble_reduce: bad argument");
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(ensamble_reduce_kernel, dim3(ew_blocks(total, 64)), dim3(64), 0, (hipStream_t)stream, means,
+                       logvars, grid, mean, logvar, posterior, S, H * W, total);
+    return mmlf_launch_status("mmlf_ensamble_reduce");
+}

@@ -1,0 +1,247 @@
+"""Host-side orchestration of the HIP kernels for the FeedForward trunk
+(reference mmlf/model/feed_forward.py:206-269 forward; autograd backward reached from
+mmlf/train/cli.py:257).  PyTorch supplies device memory and streams only; every arithmetic
+step is a call through the C ABI (include/mmlf_hip.h).
+
+Layout and indexing are described in include/mmlf_hip.h and DESIGN.md section 3.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+VAR_IDENTITY, VAR_TRANSPOSE, VAR_TRANSPOSE_FLIPH = 0, 1, 2
+BN_BLOCKS = 1024
+LOSS_BLOCKS = 1024
+
+
+def cs_of(c):
+    """channel stride (floats) used for a c-channel grid tensor: multiple of 8."""
+    return (c + 7) // 8 * 8
+
+
+class Geometry:
+    def __init__(self, B, H, W):
+        self.B, self.H, self.W = B, H, W
+        self.P, self.R = W + 2, H + 2
+        self.G = self.P * self.R
+        self.NQ = B * self.G
+        self.alloc = int(_lib.load().mmlf_grid_alloc_positions(B, H, W))
+        if self.alloc * 288 * 4 >= 2 ** 63 or self.NQ + 600 >= 2 ** 31:
+            raise ValueError('batch x image too large for 32-bit grid positions')
+
+    def buf(self, cs, device):
+        """Grid buffer with zeroed head/tail slack (the kernels write everything else)."""
+        t = torch.empty(self.alloc * cs, dtype=torch.float32, device=device)
+        t[:(self.P + 1) * cs].zero_()
+        t[self.NQ * cs:].zero_()
+        return t
+
+
+class _Workspace:
+    """Per-device scratch that is reused across calls (stream-ordered, single stream)."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, device):
+        key = (device.type, device.index)
+        ws = cls._cache.get(key)
+        if ws is None:
+            ws = cls._cache[key] = cls(device)
+        return ws
+
+    def __init__(self, device):
+        self.device = device
+        self.wgrad = None
+        self.partial = torch.empty(2 * 512 * max(BN_BLOCKS, LOSS_BLOCKS) + 8, dtype=torch.float64, device=device)
+
+    def wgrad_ws(self, cin, cout):
+        n = int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout))
+        if n < 0:
+            raise RuntimeError(f'wgrad: unsupported channels {cin}->{cout}')
+        if self.wgrad is None or self.wgrad.numel() < n:
+            self.wgrad = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self.wgrad
+
+
+def pack_filter(w, variant, dgrad):
+    cout, cin = w.shape[0], w.shape[1]
+    K, N = (cout, cin) if dgrad else (cin, cout)
+    # the kernel walks K in chunks of 8 over the channel stride of its input
+    n = int(_lib.load().mmlf_packed_filter_floats(cs_of(K), N))
+    if n < 0:
+        raise RuntimeError(f'pack_filter: unsupported channels K={K} N={N}')
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    call('mmlf_pack_filter', ptr(w), ptr(out), cout, cin, variant, int(dgrad), _lib.stream_ptr())
+    # the kernel only fills ceil(K/8) chunks; cs_of(K)/8 == ceil(K/8)
+    return out
+
+
+def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0):
+    call('mmlf_conv2x2', ptr(x), cs_in, K, ptr(packed), ptr(bias), N, ptr(out), cs_out, cs_out, out_shift,
+         vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref, _lib.stream_ptr())
+
+
+class BlockSpec:
+    def __init__(self, prefix, cin, cout, bn):
+        self.prefix, self.cin, self.cout, self.bn = prefix, cin, cout, bn
+
+
+class Trunk:
+    """Native forward/backward of in_net_hv / in_net_id / out_net for the default flags
+    (k=2, BatchNorm on, non-cross).  `params` maps state_dict keys to device tensors."""
+
+    def __init__(self, chs, in_blocks, out_blocks, views, oc, momentum, eps=1e-5):
+        self.chs, self.views, self.oc = chs, views, oc
+        self.momentum, self.eps = float(momentum), float(eps)
+        cin0 = views * 3
+        self.streams = []
+        for key, net, var in (('h', 'in_net_hv', VAR_TRANSPOSE), ('v', 'in_net_hv', VAR_IDENTITY),
+                              ('i', 'in_net_id', VAR_TRANSPOSE_FLIPH), ('d', 'in_net_id', VAR_IDENTITY)):
+            blocks = [BlockSpec(f'{net}.0', cin0, chs, True)]
+            blocks += [BlockSpec(f'{net}.{k}', chs, chs, True) for k in range(1, in_blocks)]
+            self.streams.append((key, var, blocks))
+        c = 4 * chs
+        self.out_blocks = [BlockSpec(f'out_net.{k}', c, c, True) for k in range(out_blocks - 1)]
+        self.out_blocks.append(BlockSpec(f'out_net.{out_blocks - 1}', c, oc, False))
+        if chs % 2 or cs_of(c) != c:
+            raise ValueError('native trunk needs an even model_chs with 4*model_chs a multiple of 8')
+
+    # ------------------------------------------------------------------ forward
+    def _block_fwd(self, geo, spec, var, x, cs_x, p, train, rec_list, out=None, cs_out=None, c_off=0):
+        """x: grid tensor (extent H,W at (1,1)).  Returns the block output grid tensor."""
+        dev = x.device
+        ws = _Workspace.get(dev)
+        B, H, W, P = geo.B, geo.H, geo.W, geo.P
+        cmid, cs_mid = spec.cout, cs_of(spec.cout)
+        w1, b1 = p[f'{spec.prefix}.0.weight'], p[f'{spec.prefix}.0.bias']
+        w2, b2 = p[f'{spec.prefix}.2.weight'], p[f'{spec.prefix}.2.bias']
+        pk1 = pack_filter(w1, var, False)
+        pk2 = pack_filter(w2, var, False)
+        y = geo.buf(cs_mid, dev)
+        conv(geo, x, cs_x, spec.cin, pk1, b1, cmid, y, cs_mid, 0, H + 1, W + 1, True)
+        z = geo.buf(cs_mid, dev)
+        conv(geo, y, cs_mid, cmid, pk2, b2, cmid, z, cs_mid, P + 1, H, W, False)
+        rec = {'spec': spec, 'var': var, 'x': x, 'cs_x': cs_x, 'y': y, 'z': z}
+        if not spec.bn:
+            rec_list.append(rec)
+            return z, cs_mid
+        C = spec.cout
+        coef = torch.empty(4 * C, dtype=torch.float32, device=dev)
+        scale, shift, smean, sinv = coef[:C], coef[C:2 * C], coef[2 * C:3 * C], coef[3 * C:]
+        g, bt = p[f'{spec.prefix}.3.weight'], p[f'{spec.prefix}.3.bias']
+        rm, rv = p[f'{spec.prefix}.3.running_mean'], p[f'{spec.prefix}.3.running_var']
+        if train:
+            call('mmlf_bn_stats_train', ptr(z), cs_mid, C, ptr(g), ptr(bt), ptr(rm), ptr(rv), self.momentum,
+                 self.eps, ptr(smean), ptr(sinv), ptr(scale), ptr(shift), ptr(ws.partial), BN_BLOCKS, B, H, W,
+                 _lib.stream_ptr())
+            p[f'{spec.prefix}.3.num_batches_tracked'].add_(1)
+        else:
+            call('mmlf_bn_coeffs_eval', ptr(g), ptr(bt), ptr(rm), ptr(rv), self.eps, ptr(scale), ptr(shift), C,
+                 _lib.stream_ptr())
+        if out is None:
+            cs_out = cs_mid
+            out = geo.buf(cs_out, dev)
+            c_store = cs_out
+        else:
+            c_store = C
+        call('mmlf_bn_apply_relu', ptr(z), cs_mid, C, ptr(scale), ptr(shift), ptr(out), cs_out, c_off, c_store,
+             B, H, W, _lib.stream_ptr())
+        rec.update(scale=scale, shift=shift, smean=smean, sinv=sinv)
+        rec_list.append(rec)
+        return out, cs_out
+
+    def forward(self, p, stacks, train, save):
+        """stacks: four (B, views, 3, H, W) contiguous float32 device tensors.
+        Returns (output NCHW (B,oc,H,W), ctx or None)."""
+        h = stacks[0]
+        B, n, c, H, W = h.shape
+        dev = h.device
+        geo = Geometry(B, H, W)
+        cin0 = n * c
+        tape = {'geo': geo, 'streams': [], 'out': []}
+        concat = geo.buf(4 * self.chs, dev)
+        for s, (key, var, blocks) in enumerate(self.streams):
+            x = geo.buf(cs_of(cin0), dev)
+            call('mmlf_pack_nchw', ptr(stacks[s]), cin0, ptr(x), cs_of(cin0), B, H, W, _lib.stream_ptr())
+            cs_x = cs_of(cin0)
+            recs = []
+            for k, spec in enumerate(blocks):
+                last = k == len(blocks) - 1
+                x, cs_x = self._block_fwd(geo, spec, var, x, cs_x, p, train, recs,
+                                          out=concat if last else None, cs_out=4 * self.chs, c_off=s * self.chs)
+            tape['streams'].append(recs)
+            if not save:
+                del recs[:]
+        x, cs_x = concat, 4 * self.chs
+        for spec in self.out_blocks:
+            x, cs_x = self._block_fwd(geo, spec, VAR_IDENTITY, x, cs_x, p, train, tape['out'])
+            if not save:
+                del tape['out'][:]
+        out = torch.empty((B, self.oc, H, W), dtype=torch.float32, device=dev)
+        call('mmlf_unpack_nchw', ptr(x), cs_x, ptr(out), self.oc, B, H, W, _lib.stream_ptr())
+        return out, (tape if save else None)
+
+    # ------------------------------------------------------------------ backward
+    def _block_bwd(self, geo, rec, p, grads, gy, cs_gy, c_off, need_dx, dx_out=None, cs_dx=None):
+        """gy: gradient w.r.t. the block output (grid, extent (H,W)).  Returns dX grid tensor."""
+        spec, var = rec['spec'], rec['var']
+        dev = gy.device
+        ws = _Workspace.get(dev)
+        B, H, W, P = geo.B, geo.H, geo.W, geo.P
+        C, cs_mid = spec.cout, cs_of(spec.cout)
+        x, cs_x, y, z = rec['x'], rec['cs_x'], rec['y'], rec['z']
+        pre = spec.prefix
+        sp = _lib.stream_ptr
+        if spec.bn:
+            coef = torch.empty(3 * C, dtype=torch.float32, device=dev)
+            call('mmlf_bn_bwd_reduce', ptr(gy), cs_gy, c_off, ptr(z), cs_mid, C, ptr(rec['scale']), ptr(rec['shift']),
+                 ptr(p[f'{pre}.3.weight']), ptr(rec['smean']), ptr(rec['sinv']), ptr(grads[f'{pre}.3.weight']),
+                 ptr(grads[f'{pre}.3.bias']), 1, ptr(coef), ptr(ws.partial), BN_BLOCKS, B, H, W, sp())
+            dz = geo.buf(cs_mid, dev)
+            call('mmlf_bn_bwd_apply', ptr(gy), cs_gy, c_off, ptr(z), cs_mid, C, ptr(rec['scale']), ptr(rec['shift']),
+                 ptr(rec['smean']), ptr(coef), ptr(dz), cs_mid, B, H, W, sp())
+        else:
+            assert c_off == 0 and cs_gy == cs_mid
+            dz = gy
+        w1, w2 = p[f'{pre}.0.weight'], p[f'{pre}.2.weight']
+        # conv2 (pad 0): weight/bias gradient, then data gradient fused with the ReLU mask of y
+        call('mmlf_conv2x2_wgrad', ptr(y), cs_mid, C, ptr(dz), cs_mid, C, P + 1, ptr(grads[f'{pre}.2.weight']),
+             ptr(grads[f'{pre}.2.bias']), var, 1, ptr(ws.wgrad_ws(C, C)), B, H, W, sp())
+        pk = pack_filter(w2, var, True)
+        dy = geo.buf(cs_mid, dev)
+        conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
+        del dz
+        # conv1 (pad 1)
+        call('mmlf_conv2x2_wgrad', ptr(x), cs_x, spec.cin, ptr(dy), cs_mid, C, 0, ptr(grads[f'{pre}.0.weight']),
+             ptr(grads[f'{pre}.0.bias']), var, 1, ptr(ws.wgrad_ws(spec.cin, C)), B, H, W, sp())
+        if not need_dx:
+            return None
+        pk = pack_filter(w1, var, True)
+        dx = geo.buf(cs_x, dev)
+        conv(geo, dy, cs_mid, C, pk, None, spec.cin, dx, cs_x, P + 1, H, W, False)
+        return dx
+
+    def backward(self, p, tape, grad_output, grads):
+        """grad_output: (B,oc,H,W) NCHW.  grads: dict name -> tensor, ACCUMULATED into
+        (the caller zeroes them)."""
+        geo = tape['geo']
+        dev = grad_output.device
+        B, H, W = geo.B, geo.H, geo.W
+        cs = cs_of(self.oc)
+        g = geo.buf(cs, dev)
+        call('mmlf_pack_nchw', ptr(grad_output.contiguous()), self.oc, ptr(g), cs, B, H, W, _lib.stream_ptr())
+        cs_g = cs
+        recs = tape['out']
+        while recs:
+            rec = recs.pop()
+            g = self._block_bwd(geo, rec, p, grads, g, cs_g, 0, True)
+            cs_g = rec['cs_x']
+        # g is now the gradient w.r.t. the concat buffer (cs = 4*chs); streams read channel slices
+        for s in reversed(range(4)):
+            recs = tape['streams'][s]
+            gs, cs_s, off = g, cs_g, s * self.chs
+            while recs:
+                rec = recs.pop()
+                gs = self._block_bwd(geo, rec, p, grads, gs, cs_s, off, need_dx=bool(recs))
+                cs_s, off = rec['cs_x'], 0

@@ -1,0 +1,185 @@
+"""FeedForward: drop-in for reference mmlf/model/feed_forward.py:15-305.
+
+Same constructor keywords, same ``forward(h_views, v_views, i_views, d_views)`` signature, same
+five-key output dict and the same ``state_dict`` key set, so reference
+checkpoints load unchanged and the reference's train / validate drivers can use it as is.
+
+On CUDA (= HIP on ROCm) tensors with the default flags (k=2, BatchNorm, four streams) the whole
+trunk runs in hand-written gfx950 kernels through the C ABI (engine.Trunk); there is no fallback on
+that path: a missing libmmlf_hip.so raises.  CPU tensors, and the non-default flags the README
+recipes never use (model_cross, odd ksize, model_no_batchnorm), run the module tree with stock
+torch ops ("plumbing path": BASELINE.json configs[0], CPU tests, gloo rehearsal).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr
+from .engine import Trunk
+
+
+def laplacian(x, mu, b):
+    """Laplace density, reference feed_forward.py:9-12 (kept for Ensamble and callers)."""
+    mu = mu.unsqueeze(1)
+    b = b.unsqueeze(1)
+    return 1.0 / (2.0 * b) * torch.exp(-torch.abs(x - mu) / b)
+
+
+def _conv_block(cin, cout, ksize, pad1, pad2, bn, momentum):
+    layers = [nn.Conv2d(cin, cout, ksize, padding=pad1), nn.ReLU(),
+              nn.Conv2d(cout, cout, ksize, padding=pad2)]
+    if bn is not None:
+        if bn:
+            layers.append(nn.BatchNorm2d(cout, momentum=momentum))
+        layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+class _TrunkFn(torch.autograd.Function):
+    """One autograd node for in_net_hv x2, in_net_id x2, concat and out_net."""
+
+    @staticmethod
+    def forward(ctx, module, train, h, v, i, d, *params):
+        p = module._tensor_dict()
+        save = torch.is_grad_enabled() and any(t.requires_grad for t in params)
+        with torch.no_grad():
+            out, tape = module._trunk.forward(p, [h, v, i, d], train, save)
+        ctx.module, ctx.tape = module, tape
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        module, tape = ctx.module, ctx.tape
+        if tape is None:
+            raise RuntimeError('FeedForward: backward through a forward that saved nothing')
+        ctx.tape = None
+        names = module._param_names
+        p = module._tensor_dict()
+        sizes = [p[n].numel() for n in names]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=gout.device)
+        grads, o = {}, 0
+        for n, sz in zip(names, sizes):
+            grads[n] = flat[o:o + sz].view_as(p[n])
+            o += sz
+        with torch.no_grad():
+            module._trunk.backward(p, tape, gout, grads)
+        return (None, None, None, None, None, None) + tuple(grads[n] for n in names)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, model_ksize, model_in_blocks, model_out_blocks, model_chs, model_views,
+                 model_cross, model_uncert, model_unet, model_discrete, model_no_batchnorm,
+                 model_batchnorm_momentum, val_disp_min, val_disp_max, **kwargs):
+        super().__init__()
+        if model_unet:
+            raise NotImplementedError('model_unet is outside the accelerated path (SURVEY.md section 2)')
+        assert model_in_blocks >= 1 and model_out_blocks >= 1
+        self.ksize, self.chs, self.views = model_ksize, model_chs, model_views
+        self.cross, self.uncert, self.discrete = model_cross, model_uncert, model_discrete
+        self.no_batchnorm = model_no_batchnorm
+        self.batchnorm_momentum = model_batchnorm_momentum
+        self.disp_min, self.disp_max = val_disp_min, val_disp_max
+        self.steps = (2 if model_cross else 4) * model_views * 3
+        # even kernels: pad k//2 then k//2-1 keeps the block size-preserving (feed_forward.py:86-92)
+        pad1 = model_ksize // 2
+        pad2 = model_ksize // 2 - (0 if model_ksize % 2 else 1)
+        bn = not model_no_batchnorm
+
+        def in_net():
+            blocks = [_conv_block(model_views * 3, model_chs, model_ksize, pad1, pad2, bn, model_batchnorm_momentum)]
+            blocks += [_conv_block(model_chs, model_chs, model_ksize, pad1, pad2, bn, model_batchnorm_momentum)
+                       for _ in range(model_in_blocks - 1)]
+            return nn.Sequential(*blocks)
+
+        self.in_net_hv = in_net()
+        if not model_cross:
+            self.in_net_id = in_net()
+        c = (2 if model_cross else 4) * model_chs
+        oc = 2 if model_uncert else (self.steps if model_discrete else 1)
+        blocks = [_conv_block(c, c, model_ksize, pad1, pad2, bn, model_batchnorm_momentum)
+                  for _ in range(model_out_blocks - 1)]
+        blocks.append(_conv_block(c, oc, model_ksize, pad1, pad2, None, None))
+        self.out_net = nn.Sequential(*blocks)
+        self.out_chs = oc
+
+        self._native_ok = (model_ksize == 2 and not model_cross and bn and model_chs % 2 == 0
+                           and (4 * model_chs) % 8 == 0 and 4 * model_chs <= 288 and oc <= 128)
+        self._trunk = (Trunk(model_chs, model_in_blocks, model_out_blocks, model_views, oc,
+                             model_batchnorm_momentum) if self._native_ok else None)
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self._grids = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _tensor_dict(self):
+        d = {n: t for n, t in self.named_parameters()}
+        d.update({n: t for n, t in self.named_buffers()})
+        return d
+
+    def _grid(self, kind, device):
+        key = (kind, str(device))
+        if key not in self._grids:
+            if kind == 'np':  # feed_forward.py:287-288,298-299: float64 linspace assigned to float32
+                g = torch.from_numpy(np.linspace(self.disp_min, self.disp_max, self.steps)).float()
+            else:             # dl.py:177: torch.linspace in float32
+                g = torch.linspace(self.disp_min, self.disp_max, self.steps)
+            self._grids[key] = g.to(device)
+        return self._grids[key]
+
+    def _torch_trunk(self, h, v, i, d):
+        """Plumbing path (stock torch ops on the module tree), feed_forward.py:226-269."""
+        b, n, c, hh, ww = h.shape
+        h, v = h.view(b, n * c, hh, ww), v.view(b, n * c, hh, ww)
+        feats = [self.in_net_hv(h.transpose(2, 3)).transpose(2, 3), self.in_net_hv(v)]
+        if not self.cross:
+            i, d = i.view(b, n * c, hh, ww), d.view(b, n * c, hh, ww)
+            fi = self.in_net_id(i.transpose(2, 3).flip(-1)).flip(-1).transpose(2, 3)
+            feats += [fi, self.in_net_id(d)]
+        return self.out_net(torch.cat(feats, 1))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, h_views, v_views, i_views=None, d_views=None):
+        b, n, c, hh, ww = h_views.shape
+        if h_views.is_cuda and self._native_ok:
+            _lib.load()  # raises if the HIP library is missing: no silent fallback on the GPU path
+            stacks = [h_views, v_views, i_views, d_views]
+            for t in stacks:
+                if t is None or not t.is_contiguous() or t.dtype != torch.float32 or t.shape != h_views.shape:
+                    raise ValueError('FeedForward: four contiguous float32 (b, n, 3, h, w) stacks required')
+            params = [p for _, p in self.named_parameters()]
+            output = _TrunkFn.apply(self, self.training, *stacks, *params)
+        else:
+            output = self._torch_trunk(h_views, v_views, i_views, d_views)
+
+        mean = output[:, 0]
+        scores = one_hot = posterior = logvar = None
+        native = output.is_cuda and self._native_ok
+        if self.discrete:
+            scores = output
+            if native:
+                sc = scores.detach().contiguous()
+                one_hot = torch.empty_like(sc)
+                posterior = torch.empty_like(sc)
+                mean = torch.empty((b, hh, ww), dtype=torch.float32, device=sc.device)
+                logvar = torch.empty_like(mean)
+                call('mmlf_head_dpp', ptr(sc), ptr(self._grid('torch', sc.device)), ptr(self._grid('np', sc.device)),
+                     ptr(one_hot), ptr(posterior), ptr(mean), ptr(logvar), self.steps, b, hh, ww, _lib.stream_ptr())
+            else:
+                one_hot = (torch.max(scores, 1, keepdim=True)[0] == scores).float()
+                e = torch.exp(scores)
+                posterior = e / torch.sum(e, 1, keepdim=True)
+                mean = torch.sum(self._grid('torch', scores.device).view(1, -1, 1, 1) * one_hot, 1)
+                g = self._grid('np', scores.device).view(1, -1, 1, 1)
+                logvar = torch.log(torch.sum((g - mean.unsqueeze(1)) ** 2.0 * posterior, 1))
+        if self.uncert:
+            logvar = output[:, 1]
+            if native:
+                o = output.detach().contiguous()
+                posterior = torch.empty((b, self.steps, hh, ww), dtype=torch.float32, device=o.device)
+                call('mmlf_head_upr', ptr(o), ptr(self._grid('np', o.device)), ptr(posterior), self.steps,
+                     b, hh, ww, _lib.stream_ptr())
+            else:
+                g = self._grid('np', output.device).view(1, -1, 1, 1).expand(b, self.steps, hh, ww)
+                posterior = laplacian(g, mean, torch.exp(logvar))
+        return {'mean': mean, 'logvar': logvar, 'scores': scores, 'one_hot': one_hot,
+                'posterior': posterior}

@@ -1,0 +1,236 @@
+"""GPU parity tests, kernel level: each C-ABI entry point against the CPU oracle on seeded inputs.
+Run on the MI355X box:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'these tests need the GPU box'
+    return torch.device('cuda:0')
+
+
+def grid_from_nchw(a, cs, geo, extent_plus=0, offset=1):
+    """numpy NCHW (B,C,h,w) -> flat grid buffer (alloc*cs), stored at (offset, offset)."""
+    B, C, h, w = a.shape
+    buf = np.zeros((geo.alloc, cs), np.float32)
+    g = buf[:geo.NQ].reshape(B, geo.R, geo.P, cs)
+    g[:, offset:offset + h, offset:offset + w, :C] = a.transpose(0, 2, 3, 1)
+    return buf.reshape(-1)
+
+
+def nchw_from_grid(buf, cs, C, geo, h, w, offset):
+    g = buf.reshape(geo.alloc, cs)[:geo.NQ].reshape(geo.B, geo.R, geo.P, cs)
+    return g[:, offset:offset + h, offset:offset + w, :C].transpose(0, 3, 1, 2).copy(), g
+
+
+CONV_SHAPES = [(27, 70), (70, 70), (280, 280), (280, 1), (2, 2), (280, 108), (108, 108), (8, 8), (32, 32)]
+
+
+@pytest.mark.parametrize('cin,cout', CONV_SHAPES)
+@pytest.mark.parametrize('pad', [1, 0])
+def test_conv_forward_and_border(oracle, cin, cout, pad):
+    from mmlf_amd import engine
+    dev = _dev()
+    rs = np.random.RandomState(cin * 1000 + cout + pad)
+    B, H, W = 3, 9, 13          # odd, non-square; 3*11*15 positions = 2 tiles with a ragged tail
+    geo = engine.Geometry(B, H, W)
+    w = rs.uniform(-0.5, 0.5, (cout, cin, 2, 2)).astype(np.float32)
+    b = rs.uniform(-0.5, 0.5, (cout,)).astype(np.float32)
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    if pad == 1:   # input extent (H,W) at (1,1) -> output extent (H+1,W+1) at (0,0)
+        x = rs.uniform(-1, 1, (B, cin, H, W)).astype(np.float32)
+        xg = grid_from_nchw(x, cs_in, geo, offset=1)
+        shift, vh, vw, oh, ow, ooff = 0, H + 1, W + 1, H + 1, W + 1, 0
+    else:          # input extent (H+1,W+1) at (0,0) -> output extent (H,W) at (1,1)
+        x = rs.uniform(-1, 1, (B, cin, H + 1, W + 1)).astype(np.float32)
+        xg = grid_from_nchw(x, cs_in, geo, offset=0)
+        shift, vh, vw, oh, ow, ooff = geo.P + 1, H, W, H, W, 1
+    for relu in (False, True):
+        ref = oracle.conv2x2(x, w, b, pad, relu=relu)
+        tw, tb = torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
+        pk = engine.pack_filter(tw, 0, False)
+        out = torch.full((geo.alloc * cs_out,), float('nan'), device=dev)
+        out[:(geo.P + 1) * cs_out] = 0
+        out[geo.NQ * cs_out:] = 0
+        engine.conv(geo, torch.from_numpy(xg).to(dev), cs_in, cin, pk, tb, cout, out, cs_out, shift, vh, vw, relu)
+        got, g = nchw_from_grid(out.cpu().numpy(), cs_out, cout, geo, oh, ow, ooff)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+        # everything outside the stored extent (border, pad channels, slack) must be exactly zero
+        full = out.cpu().numpy()
+        assert np.isfinite(full).all()
+        g2 = g.copy()
+        g2[:, ooff:ooff + oh, ooff:ooff + ow, :cout] = 0
+        assert not g2.any()
+        assert not full.reshape(geo.alloc, cs_out)[geo.NQ:].any()
+
+
+@pytest.mark.parametrize('variant', [0, 1, 2])
+def test_filter_variants_equal_image_transforms(oracle, variant):
+    """Transposed / transposed+flipped filters on the plain image == plain filters on the
+    transformed image (reference feed_forward.py:236-256)."""
+    from mmlf_amd import engine
+    dev = _dev()
+    rs = np.random.RandomState(variant)
+    B, S, cin, cout = 2, 12, 27, 70
+    geo = engine.Geometry(B, S, S)
+    x = rs.uniform(-1, 1, (B, cin, S, S)).astype(np.float32)
+    w = rs.uniform(-0.5, 0.5, (cout, cin, 2, 2)).astype(np.float32)
+    b = rs.uniform(-0.5, 0.5, (cout,)).astype(np.float32)
+    if variant == 0:
+        ref = oracle.conv2x2(x, w, b, 1)
+    elif variant == 1:
+        ref = oracle.conv2x2(np.ascontiguousarray(x.transpose(0, 1, 3, 2)), w, b, 1).transpose(0, 1, 3, 2)
+    else:
+        xt = np.ascontiguousarray(x.transpose(0, 1, 3, 2)[..., ::-1])
+        ref = oracle.conv2x2(xt, w, b, 1)[..., ::-1].transpose(0, 1, 3, 2)
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    pk = engine.pack_filter(torch.from_numpy(w).to(dev), variant, False)
+    out = torch.zeros(geo.alloc * cs_out, device=dev)
+    engine.conv(geo, torch.from_numpy(grid_from_nchw(x, cs_in, geo)).to(dev), cs_in, cin, pk,
+                torch.from_numpy(b).to(dev), cout, out, cs_out, 0, S + 1, S + 1, False)
+    got, _ = nchw_from_grid(out.cpu().numpy(), cs_out, cout, geo, S + 1, S + 1, 0)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('cin,cout', [(27, 70), (70, 70), (280, 280), (280, 2), (2, 2), (280, 108), (32, 8)])
+@pytest.mark.parametrize('pad', [1, 0])
+@pytest.mark.parametrize('variant', [0, 2])
+def test_conv_backward(oracle, cin, cout, pad, variant):
+    """data gradient (with fused ReLU mask), weight and bias gradients vs the oracle."""
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    if variant and cin != cout and cin != 27:
+        pytest.skip('stream variants only occur on stream layers')
+    dev = _dev()
+    rs = np.random.RandomState(cin * 7 + cout * 3 + pad + variant)
+    B, H, W = 2, 11, 9
+    geo = engine.Geometry(B, H, W)
+    w = rs.uniform(-0.5, 0.5, (cout, cin, 2, 2)).astype(np.float32)
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    ih, iw, ioff = (H, W, 1) if pad == 1 else (H + 1, W + 1, 0)
+    oh, ow, ooff = (H + 1, W + 1, 0) if pad == 1 else (H, W, 1)
+    x = rs.uniform(-1, 1, (B, cin, ih, iw)).astype(np.float32)
+    x = np.maximum(x, 0)      # plays the role of a post-ReLU activation (mask source)
+    go = rs.uniform(-1, 1, (B, cout, oh, ow)).astype(np.float32)
+    # the oracle works on the plain filter; a variant filter w_v is the master with taps permuted
+    from tests_helpers import variant_filter
+    wv = variant_filter(w, variant)
+    gin, gw_v, gb = oracle.conv2x2_bwd(x, wv, go, pad)
+    gin = gin * (x > 0)
+    gw = variant_filter(gw_v, variant, inverse=True)
+    xg = torch.from_numpy(grid_from_nchw(x, cs_in, geo, offset=ioff)).to(dev)
+    gg = torch.from_numpy(grid_from_nchw(go, cs_out, geo, offset=ooff)).to(dev)
+    tw = torch.from_numpy(w).to(dev)
+    fwd_shift = 0 if pad == 1 else geo.P + 1
+    # weight / bias gradient (accumulate on top of a known value)
+    tgw = torch.full((cout, cin, 2, 2), 0.5, device=dev)
+    tgb = torch.full((cout,), -0.25, device=dev)
+    ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout)), device=dev)
+    call('mmlf_conv2x2_wgrad', ptr(xg), cs_in, cin, ptr(gg), cs_out, cout, fwd_shift, ptr(tgw), ptr(tgb), variant, 1,
+         ptr(ws), B, H, W, _lib.stream_ptr())
+    scale = np.abs(gw).max()
+    np.testing.assert_allclose(tgw.cpu().numpy() - 0.5, gw, rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(tgb.cpu().numpy() + 0.25, gb, rtol=1e-4, atol=2e-5 * np.abs(gb).max())
+    # data gradient
+    pk = engine.pack_filter(tw, variant, True)
+    dx = torch.zeros(geo.alloc * cs_in, device=dev)
+    engine.conv(geo, gg, cs_out, cout, pk, None, cin, dx, cs_in, geo.P + 1 - fwd_shift,
+                ih, iw, False, ref=xg, cs_ref=cs_in)
+    got, _ = nchw_from_grid(dx.cpu().numpy(), cs_in, cin, geo, ih, iw, ioff)
+    np.testing.assert_allclose(got, gin, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(gin).max()))
+
+
+@pytest.mark.parametrize('C,cs_y,c_off', [(70, 72, 0), (70, 280, 70), (70, 280, 210), (280, 280, 0), (8, 32, 24)])
+def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    dev = _dev()
+    rs = np.random.RandomState(C + c_off)
+    B, H, W = 3, 10, 14
+    geo = engine.Geometry(B, H, W)
+    cs = engine.cs_of(C)
+    z = (rs.normal(size=(B, C, H, W)) * rs.uniform(0.5, 2, (1, C, 1, 1)) + rs.uniform(-3, 3, (1, C, 1, 1))).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32)
+    beta = rs.uniform(-0.5, 0.5, C).astype(np.float32)
+    rm, rv = rs.uniform(-1, 1, C).astype(np.float32), rs.uniform(0.5, 2, C).astype(np.float32)
+    rm_o, rv_o = rm.copy(), rv.copy()
+    y_ref, sm, si = oracle.bn_train(z, gamma, beta, rm_o, rv_o, 0.1)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    zg = t(grid_from_nchw(z, cs, geo))
+    tg, tb, trm, trv = t(gamma), t(beta), t(rm), t(rv)
+    coef = torch.empty(4 * C, device=dev)
+    part = torch.empty(2 * C * 1024, dtype=torch.float64, device=dev)
+    call('mmlf_bn_stats_train', ptr(zg), cs, C, ptr(tg), ptr(tb), ptr(trm), ptr(trv), 0.1, 1e-5, ptr(coef[2 * C:]),
+         ptr(coef[3 * C:]), ptr(coef), ptr(coef[C:]), ptr(part), 1024, B, H, W, _lib.stream_ptr())
+    np.testing.assert_allclose(coef[2 * C:3 * C].cpu().numpy(), sm, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(coef[3 * C:].cpu().numpy(), si, rtol=2e-6)
+    np.testing.assert_allclose(trm.cpu().numpy(), rm_o, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(trv.cpu().numpy(), rv_o, rtol=2e-6)
+    y = torch.full((geo.alloc * cs_y,), 7.0, device=dev)
+    c_store = C if cs_y != cs else cs
+    call('mmlf_bn_apply_relu', ptr(zg), cs, C, ptr(coef), ptr(coef[C:]), ptr(y), cs_y, c_off, c_store, B, H, W,
+         _lib.stream_ptr())
+    full = y.cpu().numpy().reshape(geo.alloc, cs_y)
+    got, g = nchw_from_grid(full.reshape(-1), cs_y, cs_y, geo, H, W, 1)
+    np.testing.assert_allclose(got[:, c_off:c_off + C], y_ref, rtol=1e-5, atol=2e-6)
+    assert (g[:, 0, :, c_off:c_off + C] == 0).all() and (g[:, :, 0, c_off:c_off + C] == 0).all()
+    other = np.delete(full[:geo.NQ], np.s_[c_off:c_off + c_store], axis=1)
+    assert (other == 7.0).all()      # a slice write touches nothing else
+    # eval coefficients
+    call('mmlf_bn_coeffs_eval', ptr(tg), ptr(tb), ptr(t(rm)), ptr(t(rv)), 1e-5, ptr(coef), ptr(coef[C:]), C,
+         _lib.stream_ptr())
+    ye = oracle.bn_eval(z, gamma, beta, rm, rv)
+    sc, sh = coef[:C].cpu().numpy(), coef[C:2 * C].cpu().numpy()
+    np.testing.assert_allclose(np.maximum(z * sc[None, :, None, None] + sh[None, :, None, None], 0), ye, rtol=1e-5, atol=2e-6)
+    # backward (train): gradient arrives as a channel slice of a wider buffer
+    call('mmlf_bn_stats_train', ptr(zg), cs, C, ptr(tg), ptr(tb), None, None, 0.1, 1e-5, ptr(coef[2 * C:]),
+         ptr(coef[3 * C:]), ptr(coef), ptr(coef[C:]), ptr(part), 1024, B, H, W, _lib.stream_ptr())
+    gy = rs.normal(size=(B, C, H, W)).astype(np.float32)
+    gy_masked = oracle.relu_bwd(y_ref, gy)
+    gx_ref, gg_ref, gb_ref = oracle.bn_train_bwd(z, gy_masked, gamma, sm, si)
+    wide = np.zeros((B, cs_y, H, W), np.float32)
+    wide[:, c_off:c_off + C] = gy
+    gyg = t(grid_from_nchw(wide, cs_y, geo))
+    k = torch.empty(3 * C, device=dev)
+    dgam, dbet = torch.ones(C, device=dev), torch.ones(C, device=dev)
+    call('mmlf_bn_bwd_reduce', ptr(gyg), cs_y, c_off, ptr(zg), cs, C, ptr(coef), ptr(coef[C:]), ptr(tg),
+         ptr(coef[2 * C:]), ptr(coef[3 * C:]), ptr(dgam), ptr(dbet), 1, ptr(k), ptr(part), 1024, B, H, W, _lib.stream_ptr())
+    dz = torch.full((geo.alloc * cs,), float('nan'), device=dev)
+    call('mmlf_bn_bwd_apply', ptr(gyg), cs_y, c_off, ptr(zg), cs, C, ptr(coef), ptr(coef[C:]), ptr(coef[2 * C:]),
+         ptr(k), ptr(dz), cs, B, H, W, _lib.stream_ptr())
+    np.testing.assert_allclose(dgam.cpu().numpy() - 1, gg_ref, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dbet.cpu().numpy() - 1, gb_ref, rtol=1e-4, atol=1e-4)
+    got, g = nchw_from_grid(dz.cpu().numpy(), cs, C, geo, H, W, 1)
+    np.testing.assert_allclose(got, gx_ref, rtol=1e-4, atol=1e-5)
+    assert (g[:, 0] == 0).all() and (g[:, -1] == 0).all() and (g[:, :, 0] == 0).all() and (g[:, :, -1] == 0).all()
+
+
+def test_pack_unpack_roundtrip():
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    dev = _dev()
+    rs = np.random.RandomState(0)
+    B, C, H, W = 2, 27, 7, 12
+    geo = engine.Geometry(B, H, W)
+    x = rs.uniform(-1, 1, (B, C, H, W)).astype(np.float32)
+    g = torch.full((geo.alloc * 32,), float('nan'), device=dev)
+    g[geo.NQ * 32:] = 0
+    call('mmlf_pack_nchw', ptr(torch.from_numpy(x).to(dev)), C, ptr(g), 32, B, H, W, _lib.stream_ptr())
+    np.testing.assert_array_equal(g.cpu().numpy(), grid_from_nchw(x, 32, geo))
+    back = torch.empty((B, C, H, W), device=dev)
+    call('mmlf_unpack_nchw', ptr(g), 32, ptr(back), C, B, H, W, _lib.stream_ptr())
+    np.testing.assert_array_equal(back.cpu().numpy(), x)
+
+
+def test_error_convention():
+    from mmlf_amd import _lib
+    from mmlf_amd._lib import call
+    with pytest.raises(RuntimeError, match='mmlf_conv2x2'):
+        call('mmlf_conv2x2', None, 32, 27, None, None, 70, None, 72, 72, 0, 1, 1, 1, 4, 4, 0, None, 0, None)
+    x = torch.zeros(16, device=_dev())
+    with pytest.raises(RuntimeError, match='cs_in'):
+        call('mmlf_conv2x2', x.data_ptr(), 30, 27, x.data_ptr(), None, 70, x.data_ptr(), 72, 72, 0, 1, 1, 1, 4, 4, 0,
+             None, 0, None)
