@@ -140,7 +140,7 @@ class Trunk:
             call('mmlf_bn_coeffs_eval', ptr(g), ptr(bt), ptr(rm), ptr(rv), self.eps, ptr(scale), ptr(shift), C,
                  _lib.stream_ptr())
         if out is None:
-            cs_out = cs_mid
+            cs_out, c_off = cs_mid, 0
             out = geo.buf(cs_out, dev)
             c_store = cs_out
         else:

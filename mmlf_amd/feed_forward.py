@@ -40,9 +40,8 @@ class _TrunkFn(torch.autograd.Function):
     """One autograd node for in_net_hv x2, in_net_id x2, concat and out_net."""
 
     @staticmethod
-    def forward(ctx, module, train, h, v, i, d, *params):
+    def forward(ctx, module, train, save, h, v, i, d, *params):
         p = module._tensor_dict()
-        save = torch.is_grad_enabled() and any(t.requires_grad for t in params)
         with torch.no_grad():
             out, tape = module._trunk.forward(p, [h, v, i, d], train, save)
         ctx.module, ctx.tape = module, tape
@@ -64,7 +63,7 @@ class _TrunkFn(torch.autograd.Function):
             o += sz
         with torch.no_grad():
             module._trunk.backward(p, tape, gout, grads)
-        return (None, None, None, None, None, None) + tuple(grads[n] for n in names)
+        return (None, None, None, None, None, None, None) + tuple(grads[n] for n in names)
 
 
 class FeedForward(nn.Module):
@@ -147,7 +146,8 @@ class FeedForward(nn.Module):
                 if t is None or not t.is_contiguous() or t.dtype != torch.float32 or t.shape != h_views.shape:
                     raise ValueError('FeedForward: four contiguous float32 (b, n, 3, h, w) stacks required')
             params = [p for _, p in self.named_parameters()]
-            output = _TrunkFn.apply(self, self.training, *stacks, *params)
+            save = torch.is_grad_enabled() and any(t.requires_grad for t in params)
+            output = _TrunkFn.apply(self, self.training, save, *stacks, *params)
         else:
             output = self._torch_trunk(h_views, v_views, i_views, d_views)
 

@@ -180,7 +180,8 @@ def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
     other = np.delete(full[:geo.NQ], np.s_[c_off:c_off + c_store], axis=1)
     assert (other == 7.0).all()      # a slice write touches nothing else
     # eval coefficients
-    call('mmlf_bn_coeffs_eval', ptr(tg), ptr(tb), ptr(t(rm)), ptr(t(rv)), 1e-5, ptr(coef), ptr(coef[C:]), C,
+    erm, erv = t(rm), t(rv)   # keep the tensors alive across the call
+    call('mmlf_bn_coeffs_eval', ptr(tg), ptr(tb), ptr(erm), ptr(erv), 1e-5, ptr(coef), ptr(coef[C:]), C,
          _lib.stream_ptr())
     ye = oracle.bn_eval(z, gamma, beta, rm, rv)
     sc, sh = coef[:C].cpu().numpy(), coef[C:2 * C].cpu().numpy()

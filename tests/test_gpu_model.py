@@ -135,7 +135,7 @@ def test_g2_full_size_train_step_vs_reference(variant):
         ref = g[f'grad_s/{n}']
         got = p.grad.cpu().numpy()
         got = got.reshape(-1)[::97] if got.size > 4096 else got
-        assert np.linalg.norm(got - ref) <= 3e-2 * np.linalg.norm(ref) + 1e-6, n
+        assert np.linalg.norm(got - ref) <= 3e-2 * np.linalg.norm(ref) + 5e-6, n   # floor: biases feeding BN have zero true gradient
     for k, v in m.state_dict().items():
         if 'running' in k:
             np.testing.assert_allclose(v.cpu().numpy(), g[f'post/{k}'], rtol=5e-5, atol=2e-6, err_msg=k)
