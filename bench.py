@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- 96x96 EPI patches/s, BASE fwd+bwd+Adam, global bs=512, on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (reference mmlf/train/cli.py:227-258: zero_grad, forward,
+loss, backward, Adam) over one batch of synthetic patches already resident in HBM.  The global
+batch is fixed at 512 (BASELINE.json), sharded 512/N per rank (strong scaling); one RCCL
+all-reduce of the flat gradient per step, bucketed and overlapped with backward.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BASE_KW = dict(model_ksize=2, model_in_blocks=3, model_out_blocks=8, model_chs=70, model_views=9,
+               model_cross=False, model_uncert=False, model_unet=False, model_discrete=False,
+               model_no_batchnorm=False, model_batchnorm_momentum=0.1, val_disp_min=-3.5, val_disp_max=3.5)
+# SURVEY.md section 8(d) / BASELINE.md section 3: conv MACs only, 2 FLOP/MAC, unpadded channels
+GFLOP_PER_PATCH = {'base': 268.373, 'upr': 268.437, 'dpp': 277.718}
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
+
+
+def cpu_baseline(variant, patch):
+    """The oracle (float-accumulating build of oracle/mmlf_oracle.c + numpy) timed on the host cores:
+    one fwd + loss + bwd + Adam step on a bounded sample (B=2 patches)."""
+    import numpy as np
+    from mmlf_amd import synth
+    from oracle import oracle as orc
+    kw = dict(BASE_KW, **{'upr': {'model_uncert': True}, 'dpp': {'model_discrete': True}}.get(variant, {}))
+    cores = os.cpu_count() or 1
+    os.environ['OMP_NUM_THREADS'] = str(cores)
+    orc.build()
+    state = synth.synth_state(synth.param_spec(**kw), seed=0, trained_like=False)
+    B = 2
+    stacks, gt, mask = synth.synth_inputs(B, patch, seed=0)
+    mask = mask * orc.create_mask_margin(mask.shape, 11)
+    net = orc.OracleNet(kw, state, acc='f32')
+    names = [k for k in state if state[k].dtype == np.float32 and 'running' not in k]
+
+    def one_step():
+        out = net.forward(*stacks, train=True)
+        _, dldo = orc.masked_l1(out, gt, mask)
+        grads = net.backward(net.head_grad(dldo))
+        params = {n: net.state[n] for n in names}
+        m = {n: np.zeros_like(params[n]) for n in names}
+        v = {n: np.zeros_like(params[n]) for n in names}
+        orc.adam_step(params, grads, m, v, step=1, lr=1e-3)
+
+    t0 = time.time()
+    one_step()
+    dt = time.time() - t0
+    return {'value': round(B / dt, 4), 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 step, B={B} patches {patch}x{patch}, BASE fwd+loss+bwd+Adam, oracle C/numpy float accumulate, '
+                      f'{cores} OpenMP threads, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--variant', default='base', choices=['base', 'upr', 'dpp'])
+    ap.add_argument('--global-batch', type=int, default=512)
+    ap.add_argument('--patch', type=int, default=96)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from mmlf_amd import engine
+    from mmlf_amd.feed_forward import FeedForward
+    from mmlf_amd.train import TrainStep
+
+    assert args.global_batch % world == 0
+    B = args.global_batch // world
+    kw = dict(BASE_KW, **{'upr': {'model_uncert': True}, 'dpp': {'model_discrete': True}}.get(args.variant, {}))
+    torch.manual_seed(0)
+    model = FeedForward(**kw).to(dev)
+    step = TrainStep(model, lr=1e-3, loss_margin=11)
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    stacks = [torch.rand((B, 9, 3, args.patch, args.patch), device=dev, generator=gen) for _ in range(4)]
+    gt = 4.0 * torch.rand((B, args.patch, args.patch), device=dev, generator=gen) - 2.0
+    mask = torch.ones((B, args.patch, args.patch), dtype=torch.int32, device=dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 1
+    for _ in range(args.warmup):
+        step(*stacks, gt, mask, it)
+        it += 1
+    sync()
+    engine.PROFILE = []           # (tag, flops, start_event, end_event) of the dominant conv launches
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step(*stacks, gt, mask, it)
+        it += 1
+    sync()
+    dt = time.time() - t0
+    prof, engine.PROFILE = engine.PROFILE, None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_val = float(loss)
+
+    if rank == 0:
+        value = args.global_batch * args.steps / dt
+        secs = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
+        flops = sum(f for _, f, _, _ in prof)
+        achieved = flops / secs / 1e12 if secs > 0 else 0.0
+        line = {
+            'metric': '96x96 EPI patches/sec fwd+bwd, bs=512', 'value': round(value, 3), 'unit': 'patches/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.variant.upper()} fwd+bwd+Adam, global bs={args.global_batch} ps={args.patch} '
+                                   f'synthetic EPI patches, default torch init (BASELINE.json configs[1])',
+                       'per_gpu_batch': B, 'parallelism': f'dp{world}', 'loss': round(loss_val, 6)},
+            'whole_step_tflops': round(value * GFLOP_PER_PATCH[args.variant] / 1e3, 2),
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                         'kernel': 'conv4tap_kernel<9> (280->280 forward + data-gradient launches)',
+                         'launches': len(prof), 'avg_ms': round(1e3 * secs / max(1, len(prof)), 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.variant, args.patch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -118,10 +118,15 @@ int mmlf_head_dpp(const float *scores_nchw, const float *grid_torch, const float
 /* Losses (value + gradient w.r.t. the raw out_net output, NCHW), reference mmlf/model/loss.py.
  * kind 0: MaskedL1Loss (:70-77)  1: ImprovedUncertaintyL1Loss without mask_padding (:264-294)
  *      2: MaskedCrossEntropy (:146-160) with the target built as reg_to_class(gt) (dl.py:109-131).
- * scratch: >= 2*nblocks doubles.  loss_out: one float.  grad may be NULL (value only). */
+ * scratch: >= 2*nblocks+2 doubles.  loss_out: one float.  grad may be NULL (value only).
+ * den_override (nullable, device): use *den_override instead of the local mask count as the
+ * denominator -- global_count/world_size under data parallelism, so that the rank-averaged
+ * gradient is the gradient of the GLOBAL masked mean (train/cli.py:245-255 computes the loss on
+ * the gathered batch). */
 int mmlf_loss_fwd_bwd(int kind, const float *output_nchw, int oc, const float *gt, const int32_t *mask,
                       const float *grid_torch, double half_step, float *loss_out, float *grad_nchw,
-                      double *scratch, int nblocks, int B, int H, int W, void *stream);
+                      double *scratch, int nblocks, const double *den_override, int B, int H, int W,
+                      void *stream);
 
 /* torch.optim.Adam step with default hyper-parameters (train/cli.py:117-118,258) on a flat buffer.
  * g is multiplied by grad_scale first (1/world_size after the RCCL sum all-reduce). */

@@ -378,11 +378,12 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(int kind, const float
     if (threadIdx.x == 0) { scratch[2 + 2 * blockIdx.x] = r0[0]; scratch[3 + 2 * blockIdx.x] = r1[0]; }
 }
 
-__global__ void loss_finalize_kernel(double *scratch, int nblocks, float *loss_out)
+__global__ void loss_finalize_kernel(double *scratch, int nblocks, float *loss_out, const double *den_override)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double cnt = 0, sum = 0;
     for (int b = 0; b < nblocks; ++b) { cnt += scratch[2 + 2 * b]; sum += scratch[3 + 2 * b]; }
+    if (den_override) cnt = *den_override;
     const double den = cnt == 0 ? 1.0 : cnt;
     scratch[0] = 1.0 / den;
     scratch[1] = cnt;
@@ -656,7 +657,8 @@ extern "C" int mmlf_head_dpp(const float *scores, const float *grid_torch, const
 
 extern "C" int mmlf_loss_fwd_bwd(int kind, const float *output, int oc, const float *gt, const int32_t *mask,
                                  const float *grid_torch, double half_step, float *loss_out, float *grad,
-                                 double *scratch, int nblocks, int B, int H, int W, void *stream)
+                                 double *scratch, int nblocks, const double *den_override, int B, int H, int W,
+                                 void *stream)
 {
     MMLF_CHECK_ARG(kind >= 0 && kind <= 2, "mmlf_loss_fwd_bwd: kind=%d", kind);
     MMLF_CHECK_ARG(output && gt && mask && loss_out && scratch, "mmlf_loss_fwd_bwd: null pointer");
@@ -667,7 +669,7 @@ extern "C" int mmlf_loss_fwd_bwd(int kind, const float *output, int oc, const fl
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_partial_kernel, dim3(nblocks), dim3(256), 0, st, kind, output, oc, gt, mask, grid_torch,
                        (float)half_step, scratch, H * W, total);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, scratch, nblocks, loss_out);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, scratch, nblocks, loss_out, den_override);
     if (grad)
         hipLaunchKernelGGL(loss_grad_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, kind, output, oc, gt, mask,
                            grid_torch, (float)half_step, scratch, grad, H * W, total);

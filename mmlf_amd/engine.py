@@ -77,9 +77,20 @@ def pack_filter(w, variant, dgrad):
     return out
 
 
+PROFILE = None   # bench.py sets this to a list to time the dominant conv launches with HIP events
+
+
 def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0):
+    prof = PROFILE is not None and K >= 256 and N >= 256
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call('mmlf_conv2x2', ptr(x), cs_in, K, ptr(packed), ptr(bias), N, ptr(out), cs_out, cs_out, out_shift,
          vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref, _lib.stream_ptr())
+    if prof:
+        e1.record()
+        # algorithmic FLOPs of this launch: valid output positions x N x 4 taps x K, 2 FLOP per MAC
+        PROFILE.append(('conv', 2.0 * geo.B * vh * vw * N * 4 * K, e0, e1))
 
 
 class BlockSpec:
@@ -222,9 +233,10 @@ class Trunk:
         conv(geo, dy, cs_mid, C, pk, None, spec.cin, dx, cs_x, P + 1, H, W, False)
         return dx
 
-    def backward(self, p, tape, grad_output, grads):
+    def backward(self, p, tape, grad_output, grads, on_done=None):
         """grad_output: (B,oc,H,W) NCHW.  grads: dict name -> tensor, ACCUMULATED into
-        (the caller zeroes them)."""
+        (the caller zeroes them).  on_done(key) is called when every gradient of 'out_net.k' /
+        'in_net_id' / 'in_net_hv' has been enqueued (gradient-bucket all-reduce hook)."""
         geo = tape['geo']
         dev = grad_output.device
         B, H, W = geo.B, geo.H, geo.W
@@ -237,6 +249,8 @@ class Trunk:
             rec = recs.pop()
             g = self._block_bwd(geo, rec, p, grads, g, cs_g, 0, True)
             cs_g = rec['cs_x']
+            if on_done:
+                on_done(rec['spec'].prefix)
         # g is now the gradient w.r.t. the concat buffer (cs = 4*chs); streams read channel slices
         for s in reversed(range(4)):
             recs = tape['streams'][s]
@@ -245,3 +259,5 @@ class Trunk:
                 rec = recs.pop()
                 gs = self._block_bwd(geo, rec, p, grads, gs, cs_s, off, need_dx=bool(recs))
                 cs_s, off = rec['cs_x'], 0
+            if on_done and s in (2, 0):      # shared stream nets: complete after the I (resp. H) stream
+                on_done('in_net_id' if s == 2 else 'in_net_hv')

@@ -27,7 +27,7 @@ def create_mask_margin(shape, margin=0):
     return mask
 
 
-def native_loss(kind, output, gt, mask, grid_torch=None, half_step=0.0, want_grad=True):
+def native_loss(kind, output, gt, mask, grid_torch=None, half_step=0.0, want_grad=True, den_override=None):
     """Fused loss on the raw trunk output (B,oc,H,W).  Returns (loss scalar tensor, grad or None)."""
     B, oc, H, W = output.shape
     dev = output.device
@@ -40,7 +40,7 @@ def native_loss(kind, output, gt, mask, grid_torch=None, half_step=0.0, want_gra
         grad.zero_()
     scratch = torch.empty(2 * LOSS_BLOCKS + 2, dtype=torch.float64, device=dev)
     call('mmlf_loss_fwd_bwd', kind, ptr(output), oc, ptr(gt), ptr(mask), ptr(grid_torch), float(half_step),
-         ptr(loss), ptr(grad), ptr(scratch), LOSS_BLOCKS, B, H, W, _lib.stream_ptr())
+         ptr(loss), ptr(grad), ptr(scratch), LOSS_BLOCKS, ptr(den_override), B, H, W, _lib.stream_ptr())
     return loss, grad
 
 

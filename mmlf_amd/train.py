@@ -1,0 +1,215 @@
+"""Train step: counterpart of the loop body of reference mmlf/train/cli.py:185-258.
+
+``TrainStep`` owns what the reference's loop owns around the model: the loss selection
+(train/cli.py:247-255), the 11-px loss margin (:194), the LR warm start / cooling (:233-241),
+``zero_grad -> forward -> loss -> backward -> Adam.step`` (:243-258).
+
+Data parallelism replaces ``torch.nn.DataParallel`` (train/cli.py:159): one process per GPU, each
+rank trains on its shard of the batch with replica-local BatchNorm statistics (as DataParallel
+replicas do), and ONE sum all-reduce of the flat float32 gradient crosses xGMI per step, issued per
+bucket as soon as backward has produced it (RCCL: backend "nccl"; gloo on CPU for tests).
+
+On CUDA tensors everything between the input stacks and the updated parameters runs in HIP kernels
+(engine.Trunk, mmlf_loss_fwd_bwd, mmlf_adam_step); on CPU tensors (gloo rehearsal, CPU tests) the
+module's torch plumbing path + autograd + the same flat Adam arithmetic in torch ops is used.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, dl, loss as loss_mod
+from ._lib import call, ptr
+
+KINDS = {'base': loss_mod.KIND_L1, 'upr': loss_mod.KIND_UPR, 'dpp': loss_mod.KIND_CE}
+
+
+def flatten_parameters(model):
+    """Re-point every parameter at a view of ONE flat float32 buffer (state_dict keys, shapes and
+    values unchanged).  Returns (flat, [(name, offset, numel)])."""
+    params = list(model.named_parameters())
+    dev = params[0][1].device
+    total = sum(p.numel() for _, p in params)
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    layout, o = [], 0
+    for name, p in params:
+        n = p.numel()
+        flat[o:o + n].copy_(p.detach().reshape(-1))
+        p.data = flat[o:o + n].view_as(p)
+        layout.append((name, o, n))
+        o += n
+    return flat, layout
+
+
+class GradBuckets:
+    """Contiguous slices of the flat gradient, one per out_net block / stream net, all-reduced as
+    soon as the backward pass has finished the layers they cover."""
+
+    def __init__(self, layout, group=None):
+        self.group = group
+        self.ranges = {}
+        for name, o, n in layout:
+            key = name.split('.')[0] if name.startswith('in_net') else '.'.join(name.split('.')[:2])
+            lo, hi = self.ranges.get(key, (o, o + n))
+            self.ranges[key] = (min(lo, o), max(hi, o + n))
+        self.pending = []
+        self.done = set()
+
+    def ready(self, flat_grad, key):
+        if key in self.done or key not in self.ranges:
+            return
+        self.done.add(key)
+        lo, hi = self.ranges[key]
+        self.pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self, flat_grad):
+        for key in self.ranges:
+            self.ready(flat_grad, key)
+        for w in self.pending:
+            w.wait()
+        self.pending, self.done = [], set()
+
+
+class TrainStep:
+    def __init__(self, model, lr, variant=None, warm_start=False, cooling=0, betas=(0.9, 0.999), eps=1e-8,
+                 loss_margin=11, process_group=None):
+        self.model = model
+        self.lr, self.warm_start, self.cooling = float(lr), bool(warm_start), int(cooling)
+        self.betas, self.eps, self.margin = betas, float(eps), int(loss_margin)
+        self.variant = variant or ('upr' if model.uncert else ('dpp' if model.discrete else 'base'))
+        self.flat, self.layout = flatten_parameters(model)
+        self.grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.adam_steps = 0
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self.buckets = GradBuckets(self.layout, process_group) if self.distributed else None
+        self._grads = {name: self.grad[o:o + n].view_as(dict(model.named_parameters())[name])
+                       for name, o, n in self.layout}
+        self._margin_mask = {}
+        if self.distributed:   # every replica starts from rank 0's weights and buffers (DataParallel replicate)
+            dist.broadcast(self.flat, 0, group=process_group)
+            self.sync_buffers()
+
+    # ------------------------------------------------------------------ pieces
+    def sync_buffers(self):
+        """BatchNorm buffers of rank 0 win (DataParallel keeps GPU0's running statistics)."""
+        if self.distributed:
+            for _, b in self.model.named_buffers():
+                dist.broadcast(b, 0, group=self.group)
+
+    def current_lr(self, i):
+        lr = self.lr
+        if self.warm_start and i <= 1000:            # train/cli.py:233-236 (lr = 0 at i = 0)
+            lr = self.lr * float(i) / 1000.0
+        if self.cooling > 0 and i >= self.cooling:   # train/cli.py:238-241
+            lr = self.lr / (10.0 ** (i / self.cooling - 1.0))
+        return lr
+
+    def _mask(self, mask):
+        key = (tuple(mask.shape), str(mask.device))
+        if key not in self._margin_mask:
+            self._margin_mask[key] = loss_mod.create_mask_margin(mask.shape, self.margin).to(mask.device).int()
+        return mask.int() * self._margin_mask[key]    # train/cli.py:194
+
+    def _den_override(self, mask):
+        if not self.distributed:
+            return None
+        cnt = mask.sum().double().reshape(1)
+        dist.all_reduce(cnt, group=self.group)
+        return cnt / self.world
+
+    # ------------------------------------------------------------------ the step
+    def __call__(self, h, v, i_, d, gt, mask, iteration):
+        """One optimisation step on this rank's shard.  Returns the (rank-local) loss tensor."""
+        model = self.model
+        model.train()
+        lr = self.current_lr(iteration)
+        mask = self._mask(mask)
+        den = self._den_override(mask)
+        self.grad.zero_()
+        if h.is_cuda and model._native_ok:
+            loss = self._native_fwd_bwd(h, v, i_, d, gt, mask, den)
+        else:
+            loss = self._torch_fwd_bwd(h, v, i_, d, gt, mask, den)
+        if self.distributed:
+            self.buckets.finish(self.grad)
+        self.adam_steps += 1
+        self._adam(lr, 1.0 / self.world)
+        return loss
+
+    def _native_fwd_bwd(self, h, v, i_, d, gt, mask, den):
+        model = self.model
+        p = model._tensor_dict()
+        with torch.no_grad():
+            out, tape = model._trunk.forward(p, [h, v, i_, d], True, True)
+            kind = KINDS[self.variant]
+            grid, half = None, 0.0
+            if kind == loss_mod.KIND_CE:
+                grid = model._grid('torch', out.device)
+                half = (model.disp_max - model.disp_min) / model.steps / 2.0
+            loss, gout = loss_mod.native_loss(kind, out, gt, mask, grid, half, True, den)
+            on_done = (lambda key: self.buckets.ready(self.grad, key)) if self.distributed else None
+            model._trunk.backward(p, tape, gout, self._grads, on_done)
+        return loss
+
+    def _torch_fwd_bwd(self, h, v, i_, d, gt, mask, den):
+        model = self.model
+        for _, p in model.named_parameters():
+            p.grad = None
+        out = model(h, v, i_, d)
+        if self.variant == 'upr':
+            loss = loss_mod.ImprovedUncertaintyL1Loss()(out, gt, mask, None)
+        elif self.variant == 'dpp':
+            tgt = dl.reg_to_class(gt, model.disp_min, model.disp_max, model.steps)
+            loss = loss_mod.MaskedCrossEntropy()(out, tgt, mask)
+        else:
+            loss = loss_mod.MaskedL1Loss()(out, gt, mask)
+        if den is not None:     # global masked mean: rescale the local mean to the shared denominator
+            cnt = mask.sum().double()
+            loss = loss * (cnt / den.squeeze()).float() if cnt > 0 else loss
+        loss.backward()
+        for name, p in model.named_parameters():
+            self._grads[name].copy_(p.grad)
+            p.grad = None
+        return loss.detach()
+
+    def _adam(self, lr, grad_scale):
+        b1, b2 = self.betas
+        t = self.adam_steps
+        if self.flat.is_cuda:
+            call('mmlf_adam_step', ptr(self.flat), ptr(self.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                 self.flat.numel(), lr, b1, b2, self.eps, t, grad_scale, _lib.stream_ptr())
+            return
+        with torch.no_grad():
+            g = self.grad * grad_scale
+            self.exp_avg.lerp_(g, 1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+            denom = (self.exp_avg_sq.sqrt() / math.sqrt(bc2)).add_(self.eps)
+            self.flat.addcdiv_(self.exp_avg, denom, value=-lr / bc1)
+
+    # ------------------------------------------------------------------ checkpoint compatibility
+    def optimizer_state_dict(self):
+        """A torch.optim.Adam-shaped state dict (reference dl.py:58-70 stores optimizer.state_dict())."""
+        state = {}
+        for idx, (name, o, n) in enumerate(self.layout):
+            shape = dict(self.model.named_parameters())[name].shape
+            state[idx] = {'step': torch.tensor(float(self.adam_steps)),
+                          'exp_avg': self.exp_avg[o:o + n].view(shape).clone(),
+                          'exp_avg_sq': self.exp_avg_sq[o:o + n].view(shape).clone()}
+        group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False,
+                 'fused': None, 'decoupled_weight_decay': False, 'params': list(range(len(self.layout)))}
+        return {'state': state if self.adam_steps else {}, 'param_groups': [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        for idx, (name, o, n) in enumerate(self.layout):
+            st = sd['state'].get(idx)
+            if st is None:
+                continue
+            self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            self.adam_steps = int(st['step'])
