@@ -1,0 +1,131 @@
+"""Ensamble: drop-in for reference mmlf/model/ensamble.py:9-118 (the ESE method).
+
+A 70-member shift ensemble with shared weights: for every disparity offset in
+``np.arange(disp_min, disp_max, disp_step)`` the four view stacks are sheared by that offset
+(``Shift``, reference mmlf/data/hci4d.py:894-990), the UPR model predicts (mean, logvar), and the
+members are fused per pixel (arg-min logvar) plus a Laplace-mixture posterior.
+
+On CUDA tensors: one HIP kernel shears all members at once (``mmlf_shift_views``), the members run
+through the model as ONE batch when the model is in eval mode (eval-mode BatchNorm is a per-channel
+affine map, so batching members is exact), and one kernel does the fusion (``mmlf_ensamble_reduce``).
+On CPU tensors the same arithmetic runs in torch ops, member by member.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import call, ptr
+from .feed_forward import laplacian
+
+
+def shift_table(disps, views):
+    """(shift0, shift1, 1-alpha, alpha) per (member, view), exactly as hci4d.py:934-938."""
+    half = int(views / 2)
+    tab_s = np.zeros((len(disps), views, 2), np.int32)
+    tab_w = np.zeros((len(disps), views, 2), np.float32)
+    for s, disp in enumerate(disps):
+        for k in range(views):
+            alpha, s0 = math.modf(float(disp) * (k - half))
+            alpha = abs(alpha)
+            s1 = s0 + math.copysign(1.0, s0)
+            tab_s[s, k] = (int(s0), int(s1))
+            tab_w[s, k] = (1.0 - alpha, alpha)
+    return tab_s, tab_w
+
+
+def _roll(x, s, dim):
+    # cat([x[-s:], x[:-s]]) with Python slice clamping: |s| >= size leaves x unchanged
+    return x if abs(s) >= x.shape[dim] else torch.roll(x, s, dim)
+
+
+def shift_views_torch(stacks, disp):
+    """hci4d.Shift on torch tensors (..., views, 3, H, W); returns new tensors (CPU path)."""
+    h, v, i, d = [t.clone() for t in stacks]
+    views = h.shape[-4]
+    tab_s, tab_w = shift_table([disp], views)
+    for k in range(views):
+        (s0, s1), (w0, w1) = tab_s[0, k], tab_w[0, k]
+        for t in (h, i, d):
+            x = t[..., k, :, :, :]
+            t[..., k, :, :, :] = _roll(x, int(s0), -1) * float(w0) + _roll(x, int(s1), -1) * float(w1)
+    for k in range(views):
+        (s0, s1), (w0, w1) = tab_s[0, k], tab_w[0, k]
+        for t, sign in ((v, 1), (i, -1), (d, 1)):
+            x = t[..., k, :, :, :]
+            t[..., k, :, :, :] = _roll(x, sign * int(s0), -2) * float(w0) + _roll(x, sign * int(s1), -2) * float(w1)
+    return h, v, i, d
+
+
+class Ensamble(nn.Module):
+    def __init__(self, model, val_disp_min, val_disp_max, val_disp_step, **kwarg):
+        super().__init__()
+        self.disp_min, self.disp_max, self.disp_step = val_disp_min, val_disp_max, val_disp_step
+        assert self.disp_min < self.disp_max
+        assert self.disp_step > 0.0
+        self.model = model
+        self.member_budget_bytes = 24e9     # per activation buffer when members are batched
+
+    def members(self):
+        return np.arange(self.disp_min, self.disp_max, self.disp_step)
+
+    def forward(self, h_views, v_views, i_views=None, d_views=None):
+        if i_views is None or d_views is None:
+            raise NotImplementedError('cross-only ensembles are outside the accelerated path')
+        disps = self.members()
+        S = len(disps)
+        if h_views.is_cuda:
+            means, logvars = self._members_hip(h_views, v_views, i_views, d_views, disps)
+        else:
+            means, logvars = [], []
+            for sd in disps:
+                out = self.model(*shift_views_torch((h_views, v_views, i_views, d_views), float(sd)))
+                means.append(out['mean'] + float(sd))
+                logvars.append(out['logvar'])
+            means, logvars = torch.stack(means), torch.stack(logvars)
+        b, hh, ww = means.shape[1:]
+        grid = torch.from_numpy(np.linspace(self.disp_min, self.disp_max, S)).float().to(means.device)
+        if means.is_cuda:
+            means, logvars = means.contiguous(), logvars.contiguous()
+            mean = torch.empty((b, hh, ww), dtype=torch.float32, device=means.device)
+            logvar = torch.empty_like(mean)
+            posterior = torch.empty((b, S, hh, ww), dtype=torch.float32, device=means.device)
+            call('mmlf_ensamble_reduce', ptr(means), ptr(logvars), ptr(grid), ptr(mean), ptr(logvar),
+                 ptr(posterior), S, b, hh, ww, _lib.stream_ptr())
+        else:
+            idx = torch.min(logvars, 0)[1].unsqueeze(0)
+            mean, logvar = means.gather(0, idx)[0], logvars.gather(0, idx)[0]
+            g = grid.view(1, -1, 1, 1).expand(b, S, hh, ww)
+            posterior = torch.zeros((b, S, hh, ww))
+            for k in range(S):
+                posterior += laplacian(g, means[k], torch.exp(logvars[k]))
+            posterior /= float(S)
+        return {'mean': mean, 'logvar': logvar, 'means': means, 'logvars': logvars, 'posterior': posterior}
+
+    def _members_hip(self, h, v, i, d, disps):
+        b, views, c, hh, ww = h.shape
+        S = len(disps)
+        dev = h.device
+        model = self.model
+        inner = model.module if hasattr(model, 'module') else model
+        tab_s, tab_w = shift_table(disps, views)
+        tab_s, tab_w = torch.from_numpy(tab_s).to(dev), torch.from_numpy(tab_w).to(dev)
+        per_member = (hh + 2) * (ww + 2) * 4 * max(getattr(inner, 'chs', 70), 8) * 4
+        chunk = S if not inner.training else 1
+        chunk = int(max(1, min(chunk, self.member_budget_bytes // per_member)))
+        offs = torch.from_numpy(disps.astype(np.float32)).to(dev)
+        means = torch.empty((S, b, hh, ww), dtype=torch.float32, device=dev)
+        logvars = torch.empty_like(means)
+        for bi in range(b):
+            src = [t[bi].contiguous() for t in (h, v, i, d)]
+            for s0 in range(0, S, chunk):
+                n = min(chunk, S - s0)
+                outs = [torch.empty((n, views, c, hh, ww), dtype=torch.float32, device=dev) for _ in range(4)]
+                call('mmlf_shift_views', *[ptr(t) for t in src], *[ptr(t) for t in outs],
+                     ptr(tab_s[s0:s0 + n]), ptr(tab_w[s0:s0 + n]), n, views, hh, ww, _lib.stream_ptr())
+                out = model(*outs)
+                means[s0:s0 + n, bi] = out['mean'] + offs[s0:s0 + n].view(-1, 1, 1)
+                logvars[s0:s0 + n, bi] = out['logvar']
+        return means, logvars

@@ -1,0 +1,98 @@
+"""Ensamble / Shift: CPU plumbing path and (gpu-marked) HIP path against the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TINY_KW, load_golden
+from mmlf_amd.ensamble import Ensamble, shift_table, shift_views_torch
+from mmlf_amd.feed_forward import FeedForward
+
+DISPS = (-3.5, -0.3, 0.0, 0.3, 2.5, 1.0)
+
+
+def _model(g, dev='cpu'):
+    m = FeedForward(**dict(TINY_KW, model_uncert=True))
+    m.load_state_dict({k[len('state/'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('state/')})
+    return m.to(dev)
+
+
+def _check(out, g):
+    np.testing.assert_allclose(out['means'].cpu().numpy(), g['means'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out['logvars'].cpu().numpy(), g['logvars'], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out['posterior'].cpu().numpy(), g['posterior'], rtol=3e-3, atol=1e-6)
+    assert (np.abs(out['logvar'].cpu().numpy() - g['logvar']) < 1e-4).mean() > 0.999
+    assert (np.abs(out['mean'].cpu().numpy() - g['mean']) < 1e-4).mean() > 0.99
+    assert set(out) == {'mean', 'logvar', 'means', 'logvars', 'posterior'}
+
+
+def test_shift_torch_matches_reference():
+    g = load_golden('g4_shift.npz')
+    stacks = [torch.from_numpy(g[f'in{i}']) for i in range(4)]
+    for d in DISPS:
+        got = shift_views_torch(stacks, float(d))
+        for i in range(4):
+            np.testing.assert_allclose(got[i].numpy(), g[f'shift_{d}_{i}'], rtol=1e-6, atol=1e-7, err_msg=f'{d} {i}')
+
+
+def test_shift_table_signed_zero():
+    s, w = shift_table([-0.3, 0.3], 9)
+    assert tuple(s[0, 5]) == (0, -1) and tuple(s[0, 3]) == (0, 1)      # -0.3*(+1) -> (-0.0, -1)
+    assert tuple(s[1, 5]) == (0, 1) and tuple(s[1, 3]) == (0, -1)
+    np.testing.assert_allclose(w[0, 5], (0.7, 0.3), rtol=1e-6)
+
+
+def test_ensamble_cpu_matches_reference():
+    g = load_golden('g4_ensamble.npz')
+    ens = Ensamble(_model(g), -3.5, 3.5, 0.1)
+    ens.eval()
+    assert len(ens.members()) == 70
+    with torch.no_grad():
+        out = ens(*[torch.from_numpy(g[f'in{i}']) for i in range(4)])
+    _check(out, g)
+
+
+@pytest.mark.gpu
+def test_shift_hip_matches_reference():
+    from mmlf_amd import _lib
+    from mmlf_amd._lib import call, ptr
+    g = load_golden('g4_shift.npz')
+    dev = torch.device('cuda:0')
+    src = [torch.from_numpy(g[f'in{i}'][0]).to(dev) for i in range(4)]
+    views, c, H, W = src[0].shape
+    tab_s, tab_w = shift_table(DISPS, views)
+    ts, tw = torch.from_numpy(tab_s).to(dev), torch.from_numpy(tab_w).to(dev)
+    outs = [torch.empty((len(DISPS), views, c, H, W), device=dev) for _ in range(4)]
+    call('mmlf_shift_views', *[ptr(t) for t in src], *[ptr(t) for t in outs], ptr(ts), ptr(tw), len(DISPS), views,
+         H, W, _lib.stream_ptr())
+    for k, d in enumerate(DISPS):
+        for i in range(4):
+            np.testing.assert_array_equal(outs[i][k].cpu().numpy(), g[f'shift_{d}_{i}'][0], err_msg=f'{d} {i}')
+
+
+@pytest.mark.gpu
+def test_ensamble_hip_matches_reference():
+    g = load_golden('g4_ensamble.npz')
+    dev = torch.device('cuda:0')
+    ens = Ensamble(_model(g, dev), -3.5, 3.5, 0.1)
+    ens.eval()
+    with torch.no_grad():
+        out = ens(*[torch.from_numpy(g[f'in{i}']).to(dev) for i in range(4)])
+    _check(out, g)
+    # chunked members give the same result as one batch
+    ens.member_budget_bytes = 1
+    with torch.no_grad():
+        out2 = ens(*[torch.from_numpy(g[f'in{i}']).to(dev) for i in range(4)])
+    np.testing.assert_allclose(out2['means'].cpu().numpy(), out['means'].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_validate_scene_hip():
+    from mmlf_amd.validate import validate_scene
+    g = load_golden('g4_ensamble.npz')
+    dev = torch.device('cuda:0')
+    m = _model(g, dev)
+    gt = torch.zeros((1, 24, 24), device=dev)
+    out, mse, bad = validate_scene(m, *[torch.from_numpy(g[f'in{i}']).to(dev) for i in range(4)], gt, margin=3)
+    ref = float(((out['mean'][0, 3:-3, 3:-3]) ** 2).mean())
+    np.testing.assert_allclose(float(mse), ref, rtol=1e-5)
+    assert 0.0 <= float(bad) <= 1.0
