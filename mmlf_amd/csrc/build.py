@@ -7,14 +7,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['conv.hip', 'elementwise.hip']
 LIB = os.path.join(HERE, 'libmmlf_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+# -ffp-contract=off: elementwise kernels restate float32 expressions of the reference op by op
+# (mul, mul, add); fused multiply-adds appear only where written (fmaf / MFMA).
+FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function', '-ffp-contract=off']
 
 
 def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SOURCES + ['common.h', os.path.join('..', '..', 'include', 'mmlf_hip.h')]
+    deps = SOURCES + ['common.h', 'build.py', os.path.join('..', '..', 'include', 'mmlf_hip.h')]
     return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in deps)
 
 
