@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libmmlf_hip.so')
+# MMLF_HIP_LIB selects another build of the same ABI (kernel A/B experiments); never a fallback
+LIB_PATH = os.environ.get('MMLF_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libmmlf_hip.so')
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -50,26 +50,36 @@ struct ConvArgs {
     int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
 };
 
+typedef __attribute__((address_space(3))) void lds_void_t;
+
 // 512 threads = 8 waves; tile = 256 positions x NT*32 output channels; wave w owns positions
 // [32w, 32w+32) x all channels (NT accumulator tiles of 32x32).  K is walked in chunks of 8 input
-// channels x 4 taps, double-buffered in LDS:
-//   A (activations): [seg(2)][kh(2)][260] float4  -- seg 0 = positions Q0.., seg 1 = Q0+P..
+// channels x 4 taps, double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4: no
+// staging registers; the copy of chunk c+1 is in flight while chunk c is multiplied):
+//   A (activations): [seg(2)][kh(2)][320] float4  -- seg 0 = positions Q0.., seg 1 = Q0+P..
 //   B (weights)    : [tap(4)][kh(2)][NP]  float4
-// A lane (i = lane&31, kh = lane>>5) reads ONE float4 = channels 4kh..4kh+3 of its position (A)
-// or of its output channel (B): four K=2 MFMA steps pairing channel s of half 0 with 4+s of half 1.
+// One DMA wave-instruction ("piece") writes 64 consecutive float4 slots (1 KiB); its per-lane SOURCE
+// address does the gather (A: one position per lane; B: linear).  A lane (i = lane&31, kh = lane>>5)
+// reads ONE float4 = channels 4kh..4kh+3 of its position (A) or of its output channel (B): four K=2
+// MFMA steps pairing channel s of half 0 with 4+s of half 1.
 template <int NT>
 __global__ __launch_bounds__(512) void conv4tap_kernel(ConvArgs a)
 {
     constexpr int NP = NT * 32;
-    constexpr int A_F4 = 2 * 2 * 260;
+    constexpr int A_STRIDE = 320;               // float4 slots per (seg, kh) array: 5 DMA pieces
+    constexpr int A_F4 = 4 * A_STRIDE;
     constexpr int B_F4 = 4 * 2 * NP;
     constexpr int BUF_F4 = A_F4 + B_F4;
-    constexpr int NB = (B_F4 + 511) / 512;
+    constexpr int N_A = 20;                     // DMA pieces for A per chunk
+    constexpr int N_PIECES = N_A + B_F4 / 64;   // + B pieces
+    constexpr int PER_WAVE = (N_PIECES + 7) / 8;
+    static_assert(PER_WAVE <= 8, "piece schedule covers k = t and t + 4");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *lds = reinterpret_cast<float4 *>(smem);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
     const long long Q0 = (long long)blockIdx.x * MMLF_TILE;
 
@@ -79,64 +89,100 @@ __global__ __launch_bounds__(512) void conv4tap_kernel(ConvArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-    // staging registers
-    float4 ra[3], rb[NB];
-    const int apix = tid & 255, akh = tid >> 8;
-    const float *a0 = a.in + (size_t)(Q0 + apix) * a.cs_in + 4 * akh;
-    const float *a1 = a.in + (size_t)(Q0 + a.P + apix) * a.cs_in + 4 * akh;
-    const float *a2 = a.in + (size_t)(Q0 + ((tid >> 1) & 1) * a.P + 256) * a.cs_in + 4 * (tid & 1);
+    // per-lane DMA sources of this wave's pieces j = w, w+8, ...; chunk c adds c*step floats.
+    // Destinations (float4 slot index inside a buffer) are wave-uniform.
+    const float *src[PER_WAVE];
+    int dst_f4[PER_WAVE];
+    int step[PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+        const int j = w + 8 * k;
+        if (j < N_A) {
+            const int arr = j / 5, blk = j - 5 * arr;           // arr = seg*2 + kh
+            int p = 64 * blk + lane;
+            p = p < 256 ? p : 256;                               // lanes past the tile re-read position 256
+            src[k] = a.in + (size_t)(Q0 + (arr >> 1) * a.P + p) * a.cs_in + 4 * (arr & 1);
+            dst_f4[k] = arr * A_STRIDE + 64 * blk;
+            step[k] = 8;
+        } else {
+            const int b = (j < N_PIECES ? j : N_PIECES - 1) - N_A;
+            src[k] = a.wp + (size_t)(64 * b + lane) * 4;
+            dst_f4[k] = A_F4 + 64 * b;
+            step[k] = B_F4 * 4;
+        }
+    }
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
 
-    const int seg2 = (tid >> 1) & 1, kh2 = tid & 1;
-    const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp);
-
-#define CONV_GLOAD(c)                                                                   \
-    do {                                                                                \
-        ra[0] = *reinterpret_cast<const float4 *>(a0 + 8 * (c));                        \
-        ra[1] = *reinterpret_cast<const float4 *>(a1 + 8 * (c));                        \
-        ra[2] = *reinterpret_cast<const float4 *>(a2 + 8 * (c));                        \
-        _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                \
-            const int idx = tid + 512 * j;                                              \
-            rb[j] = wp4[(size_t)(c) * B_F4 + (idx < B_F4 ? idx : B_F4 - 1)];            \
-        }                                                                               \
+    // One LDS-DMA piece.  Inline asm: with the builtin, hipcc drains vmcnt(0) before every LDS read
+    // that might alias the in-flight copy; completion is awaited by hand before the barrier.
+#define CONV_DMA_PIECE(c, buf, k)                                                                 \
+    do {                                                                                          \
+        if ((k) < PER_WAVE && w + 8 * (k) < N_PIECES) {                                           \
+            const float *g_ = src[k] + (size_t)(c) * step[k];                                     \
+            const unsigned d_ = lds_base + (unsigned)(((buf) * BUF_F4 + dst_f4[k]) * 16);         \
+            unsigned keep_;                                                                       \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"                \
+                         "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"                   \
+                         : "=&s"(keep_) : "v"(g_), "s"(d_) : "memory");                          \
+        }                                                                                         \
     } while (0)
-#define CONV_LSTORE(buf)                                                                \
-    do {                                                                                \
-        float4 *sb = lds + (buf) * BUF_F4;                                              \
-        sb[(0 * 2 + akh) * 260 + apix] = ra[0];                                         \
-        sb[(1 * 2 + akh) * 260 + apix] = ra[1];                                         \
-        if (tid < 4) sb[(seg2 * 2 + kh2) * 260 + 256] = ra[2];                          \
-        _Pragma("unroll") for (int j = 0; j < NB; ++j) {                                \
-            const int idx = tid + 512 * j;                                              \
-            if (idx < B_F4) sb[A_F4 + idx] = rb[j];                                     \
-        }                                                                               \
-    } while (0)
+#define CONV_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-    CONV_GLOAD(0);
-    CONV_LSTORE(0);
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) CONV_DMA_PIECE(0, 0, k);
+    CONV_DMA_WAIT();
     __syncthreads();
 
     for (int c = 0; c < a.nchunk; ++c) {
         const int buf = c & 1;
-        const int cn = (c + 1 < a.nchunk) ? c + 1 : c;  // last iteration reloads chunk c (discarded)
-        CONV_GLOAD(cn);
+        const bool more = c + 1 < a.nchunk;
         const float4 *base = lds + buf * BUF_F4;
+        const float4 *ap = base + kh * A_STRIDE + 32 * w + i;
+        const float4 *bp = base + A_F4 + kh * NP + i;
+        // Software pipeline over the 4 taps: ALL fragment reads of tap t+1 are issued, then the 4*NT
+        // MFMAs of tap t run back to back while those reads land (sched_barrier pins the regions;
+        // left alone, hipcc sinks each read to just before its first use).  The DMA pieces of chunk
+        // c+1 are spread over the taps, and the two waves that share a SIMD (w, w+4) issue theirs at
+        // different points of the MFMA stream.  MFMAs stay accumulator-major (4 dependent K=2 steps
+        // per accumulator): measured faster here than the independent order.
+        float4 a_cur = ap[0], b_cur[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = bp[32 * nt];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float4 av = base[((t >> 1) * 2 + kh) * 260 + 32 * w + i + (t & 1)];
+            float4 a_nxt = a_cur, b_nxt[NT];
+            if (t < 3) {
+                a_nxt = ap[((t + 1) >> 1) * 2 * A_STRIDE + ((t + 1) & 1)];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_nxt[nt] = bp[(t + 1) * 2 * NP + 32 * nt];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && w < 4) { CONV_DMA_PIECE(c + 1, buf ^ 1, t); CONV_DMA_PIECE(c + 1, buf ^ 1, t + 4); }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const float4 bv = base[A_F4 + (t * 2 + kh) * NP + 32 * nt + i];
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[nt], 0, 0, 0);
+                if (nt == NT / 2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && w >= 4) { CONV_DMA_PIECE(c + 1, buf ^ 1, t); CONV_DMA_PIECE(c + 1, buf ^ 1, t + 4); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[nt].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[nt].y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur[nt].z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur[nt].w, acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < 3) {
+                a_cur = a_nxt;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
             }
         }
-        CONV_LSTORE(buf ^ 1);
-        __syncthreads();
+        CONV_DMA_WAIT();   // this wave's pieces of chunk c+1 have landed ...
+        __syncthreads();   // ... and so have everyone else's; all reads of buffer `buf` are done
     }
-#undef CONV_GLOAD
-#undef CONV_LSTORE
+#undef CONV_DMA_PIECE
+#undef CONV_DMA_WAIT
 
     // epilogue: D[row = position][col = channel]; lane holds col i, rows (r&3)+8(r>>2)+4kh
     unsigned valid = 0;
@@ -350,7 +396,7 @@ extern "C" int mmlf_pack_filter(const float *w, float *packed, int Cout, int Cin
 template <int NT>
 static int launch_conv(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (2 * 2 * 260 + 4 * 2 * NT * 32) * sizeof(float4);
+    constexpr size_t lds = 2 * (4 * 320 + 4 * 2 * NT * 32) * sizeof(float4);
     static bool attr_done = false;  // idempotent; a benign race only repeats the call
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_kernel<NT>),
