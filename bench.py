@@ -34,7 +34,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 
 def cpu_baseline(variant, patch):
     """The oracle (float-accumulating build of oracle/mmlf_oracle.c + numpy) timed on the host cores:
-    one fwd + loss + bwd + Adam step on a bounded sample (B=2 patches)."""
+    one fwd + loss + bwd + Adam step on a bounded sample (B=8 patches)."""
     import numpy as np
     from mmlf_amd import synth
     from oracle import oracle as orc
@@ -43,7 +43,7 @@ def cpu_baseline(variant, patch):
     os.environ['OMP_NUM_THREADS'] = str(cores)
     orc.build()
     state = synth.synth_state(synth.param_spec(**kw), seed=0, trained_like=False)
-    B = 2
+    B = 8
     stacks, gt, mask = synth.synth_inputs(B, patch, seed=0)
     mask = mask * orc.create_mask_margin(mask.shape, 11)
     net = orc.OracleNet(kw, state, acc='f32')

@@ -112,18 +112,33 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
     }
 }
 
-__global__ void bn_stats_finalize_kernel(const double *__restrict__ partial, int nblocks, int C, double n,
-                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                         float *running_mean, float *running_var, double momentum, double eps,
-                                         float *save_mean, float *save_invstd, float *scale, float *shift)
+// one wave per channel: lanes stride over the per-block partials, then a shuffle reduction
+__device__ __forceinline__ void reduce_partials(const double *__restrict__ partial, int nblocks, int C, int c,
+                                                double &s0, double &s1)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        s += partial[((size_t)b * 2 + 0) * C + c];
-        ss += partial[((size_t)b * 2 + 1) * C + c];
+    double a = 0, b = 0;
+    for (int blk = threadIdx.x; blk < nblocks; blk += 64) {
+        a += partial[((size_t)blk * 2 + 0) * C + c];
+        b += partial[((size_t)blk * 2 + 1) * C + c];
     }
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+    }
+    s0 = a; s1 = b;
+}
+
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const double *__restrict__ partial, int nblocks, int C,
+                                                               double n, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, float *running_mean,
+                                                               float *running_var, double momentum, double eps,
+                                                               float *save_mean, float *save_invstd, float *scale,
+                                                               float *shift)
+{
+    const int c = blockIdx.x;
+    double s, ss;
+    reduce_partials(partial, nblocks, C, c, s, ss);
+    if (threadIdx.x != 0) return;
     const double mean = s / n;
     double var = ss / n - mean * mean;
     if (var < 0) var = 0;
@@ -152,17 +167,15 @@ __global__ void bn_coeffs_eval_kernel(const float *gamma, const float *beta, con
     shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
 }
 
-__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblocks, int C, double n,
-                                       const float *__restrict__ gamma, const float *__restrict__ invstd,
-                                       float *dgamma, float *dbeta, int accumulate, float *coef)
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblocks, int C,
+                                                             double n, const float *__restrict__ gamma,
+                                                             const float *__restrict__ invstd, float *dgamma,
+                                                             float *dbeta, int accumulate, float *coef)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double sg = 0, sgx = 0;
-    for (int b = 0; b < nblocks; ++b) {
-        sg += partial[((size_t)b * 2 + 0) * C + c];
-        sgx += partial[((size_t)b * 2 + 1) * C + c];
-    }
+    const int c = blockIdx.x;
+    double sg, sgx;
+    reduce_partials(partial, nblocks, C, c, sg, sgx);
+    if (threadIdx.x != 0) return;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
     const double k1 = (double)(gamma ? gamma[c] : 1.f) * invstd[c];
@@ -550,7 +563,7 @@ extern "C" int mmlf_bn_stats_train(const float *z, int cs, int C, const float *g
     hipLaunchKernelGGL((bn_reduce_kernel<false, 4>), dim3(nblocks), dim3(256), 0, st, z, cs, nullptr, 0, 0, nullptr,
                        nullptr, nullptr, nullptr, C, partial, B, H, W);
     const double n = (double)B * H * W;
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblocks, C, n, gamma,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, partial, nblocks, C, n, gamma,
                        beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
     return mmlf_launch_status("mmlf_bn_stats_train");
 }
@@ -598,7 +611,7 @@ extern "C" int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const f
     else
         hipLaunchKernelGGL((bn_reduce_kernel<true, 2>), dim3(nblocks), dim3(256), 0, st, z, cs_z, gy, cs_gy, c_off,
                            scale, shift, save_mean, save_invstd, C, partial, B, H, W);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, partial, nblocks, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, nblocks, C,
                        (double)B * H * W, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
     return mmlf_launch_status("mmlf_bn_bwd_reduce");
 }
