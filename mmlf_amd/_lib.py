@@ -24,6 +24,9 @@ SIGNATURES = {
     'mmlf_wgrad_workspace_floats': (_i64, [_i, _i]),
     'mmlf_pack_filter': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_conv2x2': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    'mmlf_packed_filter_split_bytes': (_i64, [_i, _i]),
+    'mmlf_pack_filter_split': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_conv2x2_split': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'mmlf_conv2x2_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     'mmlf_bn_stats_train': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_bn_coeffs_eval': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _vp]),

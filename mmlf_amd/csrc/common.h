@@ -46,7 +46,8 @@ static inline Grid make_grid(int B, int H, int W)
     return g;
 }
 
-static inline long long grid_alloc_positions(const Grid &g) { return g.NQpad + g.P + 8; }
+// slack: taps reach P+1 past a tile; the split kernel's last DMA piece reads 64 positions more
+static inline long long grid_alloc_positions(const Grid &g) { return g.NQpad + g.P + 8 + 64; }
 
 // supported MFMA N-tile counts (32 output channels each)
 static inline int pick_nt(int N)

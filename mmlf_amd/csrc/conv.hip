@@ -50,7 +50,232 @@ struct ConvArgs {
     int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
 };
 
+// epilogue shared by the f32 and the split-bf16 kernels: D[row = position][col = channel]; a lane
+// holds column i of every N tile and rows (r&3)+8(r>>2)+4kh of its wave's 32 positions.
+template <int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&acc)[NT], long long Q0, int w, int i,
+                                              int kh)
+{
+    unsigned valid = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = (int)Q0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int rem = q % a.G;
+        const int y = rem / a.P, x = rem - y * a.P;
+        if (q < a.NQ && y < a.vh && x < a.vw) valid |= 1u << r;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ch = 32 * nt + i;
+        if (ch >= a.n_store) continue;
+        const float bv = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long q = Q0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh + a.out_shift;
+            float v = acc[nt][r] + bv;
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.ref) v = (a.ref[(size_t)q * a.cs_ref + ch] > 0.f) ? v : 0.f;
+            v = (valid >> r & 1) ? v : 0.f;
+            a.out[(size_t)q * a.cs_out + ch] = v;
+        }
+    }
+}
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float x)
+{
+    unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf16_bits_to_float(unsigned h) { return __uint_as_float(h << 16); }
+
+// x = hi + mid + lo exactly (three bf16, round-to-nearest-even residual chain)
+__device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, unsigned &lo)
+{
+    hi = bf16_rne_bits(x);
+    const float r1 = x - bf16_bits_to_float(hi);
+    mid = bf16_rne_bits(r1);
+    lo = bf16_rne_bits(r1 - bf16_bits_to_float(mid));
+}
+
+// split-precision filter packing: [chunk][u(2)][plane(3)][kh(2)][NP][8 bf16], tap = 2u+kh, k = 8*chunk+j
+__global__ void pack_filter_split_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Cout,
+                                         int Cin, int variant, int dgrad, int nchunk, int NP)
+{
+    const long long total = (long long)nchunk * 2 * 2 * NP * 8;   // one thread per (chunk,u,kh,n,j)
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int j = idx & 7;
+        long long r = idx >> 3;
+        const int n = r % NP; r /= NP;
+        const int kh = r & 1; r >>= 1;
+        const int u = r & 1; r >>= 1;
+        const int c = (int)r;
+        const int k = 8 * c + j, t = 2 * u + kh;
+        int ci, co, tsrc;
+        if (!dgrad) { ci = k; co = n; tsrc = t; }
+        else { co = k; ci = n; tsrc = 3 - t; }
+        float v = 0.f;
+        if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 4 + master_tap(tsrc, variant)];
+        unsigned p[3];
+        split3(v, p[0], p[1], p[2]);
+        for (int pl = 0; pl < 3; ++pl)
+            out[((((size_t)(c * 2 + u) * 3 + pl) * 2 + kh) * NP + n) * 8 + j] = (unsigned short)p[pl];
+    }
+}
+
 typedef __attribute__((address_space(3))) void lds_void_t;
+
+// ---------------------------------------------------------------------------------------------
+// forward / data-gradient kernel, split-bf16 arithmetic ("bf16x6"):
+// every f32 operand is split EXACTLY into three bf16 (hi+mid+lo) and each product is evaluated as the
+// six leading cross terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation (dropped terms are
+// <= 2^-26 relative).  Measured on gfx950 (scratch/bf16x6.hip): error vs a double reference
+// 1.4e-8*sum|a*b| mean, 1.0e-7 max at K=1120 -- slightly BELOW the f32 MFMA fma chain (1.7e-8 /
+// 1.9e-7) -- at 16/6 = 2.67x the f32 MFMA rate.  Same tile shape and LDS-DMA pipeline as
+// conv4tap_kernel; per chunk (8 channels x 4 taps) the K=32 slice is two MFMA K-steps (u = 0,1):
+// lanes 0-31 carry tap 2u, lanes 32-63 tap 2u+1, 8 channels each.
+//   A: [seg(2)][channel half(2)][320] float4 (f32 activations, split in registers)
+//   B: [u(2)][plane(3)][kh(2)][NP] x 16 B    (weights pre-split by pack_filter_split_kernel)
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512) void conv4tap_x6_kernel(ConvArgs a)
+{
+    constexpr int NP = NT * 32;
+    constexpr int A_STRIDE = 320;
+    constexpr int A_F4 = 4 * A_STRIDE;
+    constexpr int B_F4 = 12 * NP;
+    constexpr int BUF_F4 = A_F4 + B_F4;
+    constexpr int N_A = 20;
+    constexpr int N_PIECES = N_A + B_F4 / 64;
+    constexpr int PER_WAVE = (N_PIECES + 7) / 8;
+    constexpr int PER_SLOT = (PER_WAVE + 1) / 2;
+    constexpr int G = 2 * NT;                   // MFMA groups (6 MFMAs each) per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *lds = reinterpret_cast<float4 *>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const long long Q0 = (long long)blockIdx.x * MMLF_TILE;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    // DMA addressing: a piece = wave-uniform 64-bit base (SGPRs) + one shared per-lane byte offset
+    const unsigned voff_a = (unsigned)lane * (unsigned)a.cs_in * 4u;   // A pieces: lane = position
+    const unsigned voff_b = (unsigned)lane * 16u;                      // B pieces: linear
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
+    const char *in_base = reinterpret_cast<const char *>(a.in) + (size_t)Q0 * a.cs_in * 4;
+    const char *wp_base = reinterpret_cast<const char *>(a.wp);
+
+#define X6_DMA_PIECE(c, buf, k)                                                                          \
+    do {                                                                                                 \
+        const int j_ = w + 8 * (k);                                                                      \
+        if ((k) < PER_WAVE && j_ < N_PIECES) {                                                           \
+            const char *sb_;                                                                             \
+            unsigned vo_, d_;                                                                            \
+            if (j_ < N_A) {                                                                              \
+                const int arr_ = j_ / 5, blk_ = j_ - 5 * arr_;                                           \
+                sb_ = in_base + ((size_t)((arr_ >> 1) * a.P + 64 * blk_) * a.cs_in + 4 * (arr_ & 1) + 8 * (c)) * 4; \
+                vo_ = voff_a;                                                                            \
+                d_ = (unsigned)(arr_ * A_STRIDE + 64 * blk_);                                            \
+            } else {                                                                                     \
+                sb_ = wp_base + ((size_t)(c) * B_F4 + 64 * (j_ - N_A)) * 16;                             \
+                vo_ = voff_b;                                                                            \
+                d_ = (unsigned)(A_F4 + 64 * (j_ - N_A));                                                 \
+            }                                                                                            \
+            d_ = lds_base + ((buf) * BUF_F4 + d_) * 16u;                                                 \
+            unsigned keep_;                                                                              \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                       \
+                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"                           \
+                         : "=&s"(keep_) : "v"(vo_), "s"(sb_), "s"(d_) : "memory");                      \
+        }                                                                                                \
+    } while (0)
+#define X6_DMA_SLOT(c, buf, slot)                                                                        \
+    do {                                                                                                 \
+        _Pragma("unroll") for (int k_ = 0; k_ < PER_SLOT; ++k_) X6_DMA_PIECE(c, buf, (slot) * PER_SLOT + k_); \
+    } while (0)
+#define X6_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+    X6_DMA_SLOT(0, 0, 0);
+    X6_DMA_SLOT(0, 0, 1);
+    X6_DMA_WAIT();
+    __syncthreads();
+
+    for (int c = 0; c < a.nchunk; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < a.nchunk;
+        const float4 *base = lds + buf * BUF_F4;
+        const float4 *ap = base + 32 * w + i + kh;             // + (u*2 + half) * A_STRIDE
+        const bf16x8 *bp = reinterpret_cast<const bf16x8 *>(base + A_F4) + kh * NP + i;   // + ((u*3+pl)*2)*NP + 32nt
+
+        // raw f32 activations of both K-steps (8 channels of this lane's tap position each)
+        float4 ra[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) ra[u][hf] = ap[(u * 2 + hf) * A_STRIDE];
+        bf16x8 bq[3][3];                                       // rotating [slot][plane] weight fragments
+#pragma unroll
+        for (int g0 = 0; g0 < 2; ++g0)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bq[g0][pl] = bp[(((g0 / NT) * 3 + pl) * 2) * NP + 32 * (g0 % NT)];
+        bf16x8 asp[2][3];                                      // [u][plane] split activations
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int u = g / NT, nt = g % NT;
+            if (g + 2 < G) {
+                const int g2 = g + 2;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bq[g2 % 3][pl] = bp[(((g2 / NT) * 3 + pl) * 2) * NP + 32 * (g2 % NT)];
+            }
+            if (g == 0 || g == 1) {                            // split step g's activations (VALU)
+                const float xs[8] = {ra[g][0].x, ra[g][0].y, ra[g][0].z, ra[g][0].w,
+                                     ra[g][1].x, ra[g][1].y, ra[g][1].z, ra[g][1].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    unsigned h_, m_, l_;
+                    split3(xs[e], h_, m_, l_);
+                    asp[g][0][e] = (short)h_; asp[g][1][e] = (short)m_; asp[g][2][e] = (short)l_;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                if (w < 4) {
+                    if (g == 0) X6_DMA_SLOT(c + 1, buf ^ 1, 0);
+                    if (g == NT) X6_DMA_SLOT(c + 1, buf ^ 1, 1);
+                } else {
+                    if (g == NT / 2) X6_DMA_SLOT(c + 1, buf ^ 1, 0);
+                    if (g == NT + NT / 2) X6_DMA_SLOT(c + 1, buf ^ 1, 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // six cross terms, small ones first
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][2], bq[g % 3][0], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][0], bq[g % 3][2], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][1], bq[g % 3][1], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][1], bq[g % 3][0], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][0], bq[g % 3][1], acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][0], bq[g % 3][0], acc[nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        X6_DMA_WAIT();
+        __syncthreads();
+    }
+#undef X6_DMA_PIECE
+#undef X6_DMA_SLOT
+#undef X6_DMA_WAIT
+    conv_epilogue<NT>(a, acc, Q0, w, i, kh);
+}
+
 
 // 512 threads = 8 waves; tile = 256 positions x NT*32 output channels; wave w owns positions
 // [32w, 32w+32) x all channels (NT accumulator tiles of 32x32).  K is walked in chunks of 8 input
@@ -184,30 +409,7 @@ __global__ __launch_bounds__(512) void conv4tap_kernel(ConvArgs a)
 #undef CONV_DMA_PIECE
 #undef CONV_DMA_WAIT
 
-    // epilogue: D[row = position][col = channel]; lane holds col i, rows (r&3)+8(r>>2)+4kh
-    unsigned valid = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = (int)Q0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int rem = q % a.G;
-        const int y = rem / a.P, x = rem - y * a.P;
-        if (q < a.NQ && y < a.vh && x < a.vw) valid |= 1u << r;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int ch = 32 * nt + i;
-        if (ch >= a.n_store) continue;
-        const float bv = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long long q = Q0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh + a.out_shift;
-            float v = acc[nt][r] + bv;
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (a.ref) v = (a.ref[(size_t)q * a.cs_ref + ch] > 0.f) ? v : 0.f;
-            v = (valid >> r & 1) ? v : 0.f;
-            a.out[(size_t)q * a.cs_out + ch] = v;
-        }
-    }
+    conv_epilogue<NT>(a, acc, Q0, w, i, kh);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,4 +678,73 @@ extern "C" int mmlf_conv2x2_wgrad(const float *in, int cs_in, int Cin, const flo
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw, gb, Cin,
                        Cout, a.nslice * 32, nt * 32, a.nsplit, variant, accumulate);
     return mmlf_launch_status("mmlf_conv2x2_wgrad(reduce)");
+}
+
+// ------------------------------------------------------------------ split-bf16 ("bf16x6") entry points
+extern "C" int64_t mmlf_packed_filter_split_bytes(int K, int N)
+{
+    const int nt = pick_nt(N);
+    if (nt < 0 || K <= 0) return -1;
+    return (int64_t)((K + 7) / 8) * 12 * (nt * 32) * 16;
+}
+
+extern "C" int mmlf_pack_filter_split(const float *w, void *packed, int Cout, int Cin, int variant, int dgrad,
+                                      void *stream)
+{
+    MMLF_CHECK_ARG(w && packed, "mmlf_pack_filter_split: null pointer");
+    MMLF_CHECK_ARG(variant >= 0 && variant <= 2, "mmlf_pack_filter_split: bad variant %d", variant);
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const int nt = pick_nt(N);
+    MMLF_CHECK_ARG(nt > 0, "mmlf_pack_filter_split: N=%d not supported (max 288)", N);
+    const int nchunk = (K + 7) / 8, NP = nt * 32;
+    const long long total = (long long)nchunk * 32 * NP;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_filter_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       (unsigned short *)packed, Cout, Cin, variant, dgrad, nchunk, NP);
+    return mmlf_launch_status("mmlf_pack_filter_split");
+}
+
+template <int NT>
+static int launch_conv_x6(const ConvArgs &a, long long ntiles, hipStream_t st)
+{
+    constexpr size_t lds = 2 * (4 * 320 + 12 * NT * 32) * sizeof(float4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv4tap_x6_kernel<NT>, dim3((unsigned)ntiles), dim3(512), lds, st, a);
+    return mmlf_launch_status("mmlf_conv2x2_split");
+}
+
+extern "C" int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
+                                  float *out, int cs_out, int N_store, int out_shift, int vh, int vw, int B, int H,
+                                  int W, int relu, const float *relu_ref, int cs_ref, void *stream)
+{
+    MMLF_CHECK_ARG(in && packed && out, "mmlf_conv2x2_split: null pointer");
+    MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0, "mmlf_conv2x2_split: bad shape B=%d H=%d W=%d", B, H, W);
+    MMLF_CHECK_ARG(cs_in > 0 && cs_in % 8 == 0, "mmlf_conv2x2_split: cs_in=%d must be a multiple of 8", cs_in);
+    MMLF_CHECK_ARG(K > 0 && (K + 7) / 8 * 8 == cs_in, "mmlf_conv2x2_split: K=%d does not match cs_in=%d", K, cs_in);
+    const int nt = pick_nt(N);
+    MMLF_CHECK_ARG(nt > 0, "mmlf_conv2x2_split: N=%d not supported (max 288)", N);
+    MMLF_CHECK_ARG(N_store > 0 && N_store <= cs_out && N_store <= nt * 32,
+                   "mmlf_conv2x2_split: N_store=%d vs cs_out=%d NP=%d", N_store, cs_out, nt * 32);
+    Grid g = make_grid(B, H, W);
+    MMLF_CHECK_ARG(out_shift >= 0 && out_shift <= g.P + 1, "mmlf_conv2x2_split: out_shift=%d", out_shift);
+    MMLF_CHECK_ARG(!relu_ref || cs_ref >= N_store, "mmlf_conv2x2_split: cs_ref=%d < N_store", cs_ref);
+    MMLF_CHECK_ARG((long long)cs_in * 4 * 64 < (1ll << 31), "mmlf_conv2x2_split: cs_in too large");
+    ConvArgs a;
+    a.in = in; a.wp = reinterpret_cast<const float *>(packed); a.bias = bias; a.out = out; a.ref = relu_ref;
+    a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
+    a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
+    const long long ntiles = g.NQpad / MMLF_TILE;
+    hipStream_t st = (hipStream_t)stream;
+    switch (nt) {
+    case 1: return launch_conv_x6<1>(a, ntiles, st);
+    case 3: return launch_conv_x6<3>(a, ntiles, st);
+    case 4: return launch_conv_x6<4>(a, ntiles, st);
+    default: return launch_conv_x6<9>(a, ntiles, st);
+    }
 }

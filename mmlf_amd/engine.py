@@ -5,6 +5,8 @@ step is a call through the C ABI (include/mmlf_hip.h).
 
 Layout and indexing are described in include/mmlf_hip.h and DESIGN.md section 3.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -64,9 +66,20 @@ class _Workspace:
         return self.wgrad
 
 
+# 'bf16x6': split-precision MFMA (f32-equivalent accuracy, 2.67x the f32 MFMA rate); 'f32': exact-f32 MFMA
+CONV_MODE = os.environ.get('MMLF_CONV_MODE', 'bf16x6')
+
+
 def pack_filter(w, variant, dgrad):
     cout, cin = w.shape[0], w.shape[1]
     K, N = (cout, cin) if dgrad else (cin, cout)
+    if CONV_MODE == 'bf16x6':
+        n = int(_lib.load().mmlf_packed_filter_split_bytes(cs_of(K), N))
+        if n < 0:
+            raise RuntimeError(f'pack_filter: unsupported channels K={K} N={N}')
+        out = torch.empty(n // 4, dtype=torch.float32, device=w.device)
+        call('mmlf_pack_filter_split', ptr(w), ptr(out), cout, cin, variant, int(dgrad), _lib.stream_ptr())
+        return out
     # the kernel walks K in chunks of 8 over the channel stride of its input
     n = int(_lib.load().mmlf_packed_filter_floats(cs_of(K), N))
     if n < 0:
@@ -85,7 +98,7 @@ def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call('mmlf_conv2x2', ptr(x), cs_in, K, ptr(packed), ptr(bias), N, ptr(out), cs_out, cs_out, out_shift,
+    call('mmlf_conv2x2_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2', ptr(x), cs_in, K, ptr(packed), ptr(bias), N, ptr(out), cs_out, cs_out, out_shift,
          vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref, _lib.stream_ptr())
     if prof:
         e1.record()
