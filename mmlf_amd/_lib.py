@@ -28,6 +28,7 @@ SIGNATURES = {
     'mmlf_pack_filter_split': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_conv2x2_split': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'mmlf_conv2x2_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    'mmlf_conv2x2_wgrad_split': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     'mmlf_bn_stats_train': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_bn_coeffs_eval': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _vp]),
     'mmlf_bn_apply_relu': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

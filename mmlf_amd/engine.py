@@ -230,14 +230,15 @@ class Trunk:
             dz = gy
         w1, w2 = p[f'{pre}.0.weight'], p[f'{pre}.2.weight']
         # conv2 (pad 0): weight/bias gradient, then data gradient fused with the ReLU mask of y
-        call('mmlf_conv2x2_wgrad', ptr(y), cs_mid, C, ptr(dz), cs_mid, C, P + 1, ptr(grads[f'{pre}.2.weight']),
+        wg = 'mmlf_conv2x2_wgrad_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad'
+        call(wg, ptr(y), cs_mid, C, ptr(dz), cs_mid, C, P + 1, ptr(grads[f'{pre}.2.weight']),
              ptr(grads[f'{pre}.2.bias']), var, 1, ptr(ws.wgrad_ws(C, C)), B, H, W, sp())
         pk = pack_filter(w2, var, True)
         dy = geo.buf(cs_mid, dev)
         conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
         del dz
         # conv1 (pad 1)
-        call('mmlf_conv2x2_wgrad', ptr(x), cs_x, spec.cin, ptr(dy), cs_mid, C, 0, ptr(grads[f'{pre}.0.weight']),
+        call(wg, ptr(x), cs_x, spec.cin, ptr(dy), cs_mid, C, 0, ptr(grads[f'{pre}.0.weight']),
              ptr(grads[f'{pre}.0.bias']), var, 1, ptr(ws.wgrad_ws(spec.cin, C)), B, H, W, sp())
         if not need_dx:
             return None

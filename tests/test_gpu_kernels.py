@@ -31,8 +31,10 @@ CONV_SHAPES = [(27, 70), (70, 70), (280, 280), (280, 1), (2, 2), (280, 108), (10
 
 @pytest.mark.parametrize('cin,cout', CONV_SHAPES)
 @pytest.mark.parametrize('pad', [1, 0])
-def test_conv_forward_and_border(oracle, cin, cout, pad):
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6'])
+def test_conv_forward_and_border(oracle, cin, cout, pad, mode, monkeypatch):
     from mmlf_amd import engine
+    monkeypatch.setattr(engine, 'CONV_MODE', mode)
     dev = _dev()
     rs = np.random.RandomState(cin * 1000 + cout + pad)
     B, H, W = 3, 9, 13          # odd, non-square; 3*11*15 positions = 2 tiles with a ragged tail
@@ -98,12 +100,14 @@ def test_filter_variants_equal_image_transforms(oracle, variant):
 @pytest.mark.parametrize('cin,cout', [(27, 70), (70, 70), (280, 280), (280, 2), (2, 2), (280, 108), (32, 8)])
 @pytest.mark.parametrize('pad', [1, 0])
 @pytest.mark.parametrize('variant', [0, 2])
-def test_conv_backward(oracle, cin, cout, pad, variant):
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6'])
+def test_conv_backward(oracle, cin, cout, pad, variant, mode, monkeypatch):
     """data gradient (with fused ReLU mask), weight and bias gradients vs the oracle."""
     from mmlf_amd import engine, _lib
     from mmlf_amd._lib import call, ptr
     if variant and cin != cout and cin != 27:
         pytest.skip('stream variants only occur on stream layers')
+    monkeypatch.setattr(engine, 'CONV_MODE', mode)
     dev = _dev()
     rs = np.random.RandomState(cin * 7 + cout * 3 + pad + variant)
     B, H, W = 2, 11, 9
@@ -129,8 +133,8 @@ def test_conv_backward(oracle, cin, cout, pad, variant):
     tgw = torch.full((cout, cin, 2, 2), 0.5, device=dev)
     tgb = torch.full((cout,), -0.25, device=dev)
     ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout)), device=dev)
-    call('mmlf_conv2x2_wgrad', ptr(xg), cs_in, cin, ptr(gg), cs_out, cout, fwd_shift, ptr(tgw), ptr(tgb), variant, 1,
-         ptr(ws), B, H, W, _lib.stream_ptr())
+    call('mmlf_conv2x2_wgrad_split' if mode == 'bf16x6' else 'mmlf_conv2x2_wgrad', ptr(xg), cs_in, cin, ptr(gg),
+         cs_out, cout, fwd_shift, ptr(tgw), ptr(tgb), variant, 1, ptr(ws), B, H, W, _lib.stream_ptr())
     scale = np.abs(gw).max()
     np.testing.assert_allclose(tgw.cpu().numpy() - 0.5, gw, rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(tgb.cpu().numpy() + 0.25, gb, rtol=1e-4, atol=2e-5 * np.abs(gb).max())
