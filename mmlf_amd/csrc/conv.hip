@@ -99,6 +99,24 @@ __device__ __forceinline__ void split3(float x, unsigned &hi, unsigned &mid, uns
     lo = bf16_rne_bits(r1 - bf16_bits_to_float(mid));
 }
 
+// two floats -> two bf16 (RNE) packed in one dword (a low, b high): one v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
+{
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// (a, b) = hi + mid + lo exactly, each plane packed like cvt_pk_bf16: 5.5 VALU ops per element
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xFFFF0000u);
+    m = cvt_pk_bf16(ra, rb);
+    l = cvt_pk_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xFFFF0000u));
+}
+
 // split-precision filter packing: [chunk][u(2)][plane(3)][kh(2)][NP][8 bf16], tap = 2u+kh, k = 8*chunk+j
 __global__ void pack_filter_split_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Cout,
                                          int Cin, int variant, int dgrad, int nchunk, int NP)
@@ -238,14 +256,16 @@ __global__ __launch_bounds__(512) void conv4tap_x6_kernel(ConvArgs a)
                     bq[g2 % 3][pl] = bp[(((g2 / NT) * 3 + pl) * 2) * NP + 32 * (g2 % NT)];
             }
             if (g == 0 || g == 1) {                            // split step g's activations (VALU)
-                const float xs[8] = {ra[g][0].x, ra[g][0].y, ra[g][0].z, ra[g][0].w,
-                                     ra[g][1].x, ra[g][1].y, ra[g][1].z, ra[g][1].w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    unsigned h_, m_, l_;
-                    split3(xs[e], h_, m_, l_);
-                    asp[g][0][e] = (short)h_; asp[g][1][e] = (short)m_; asp[g][2][e] = (short)l_;
-                }
+                unsigned hh[4], mm[4], ll[4];
+                split3_pair(ra[g][0].x, ra[g][0].y, hh[0], mm[0], ll[0]);
+                split3_pair(ra[g][0].z, ra[g][0].w, hh[1], mm[1], ll[1]);
+                split3_pair(ra[g][1].x, ra[g][1].y, hh[2], mm[2], ll[2]);
+                split3_pair(ra[g][1].z, ra[g][1].w, hh[3], mm[3], ll[3]);
+                const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vm = {mm[0], mm[1], mm[2], mm[3]},
+                              vl = {ll[0], ll[1], ll[2], ll[3]};
+                asp[g][0] = __builtin_bit_cast(bf16x8, vh);
+                asp[g][1] = __builtin_bit_cast(bf16x8, vm);
+                asp[g][2] = __builtin_bit_cast(bf16x8, vl);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
@@ -551,13 +571,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const char *lds_row0, int row_stride_b
 
 __device__ __forceinline__ void split_store4(float4 v, char *p0, int plane_stride_bytes)
 {
-    const float xs[4] = {v.x, v.y, v.z, v.w};
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split3(xs[e], h[e], m[e], l[e]);
-    *reinterpret_cast<uint2 *>(p0) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    *reinterpret_cast<uint2 *>(p0 + plane_stride_bytes) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-    *reinterpret_cast<uint2 *>(p0 + 2 * plane_stride_bytes) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3_pair(v.x, v.y, h0, m0, l0);
+    split3_pair(v.z, v.w, h1, m1, l1);
+    *reinterpret_cast<uint2 *>(p0) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(p0 + plane_stride_bytes) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2 *>(p0 + 2 * plane_stride_bytes) = make_uint2(l0, l1);
 }
 
 template <int NT>
