@@ -157,8 +157,10 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 //   A: [seg(2)][channel half(2)][320] float4 (f32 activations, split in registers)
 //   B: [u(2)][plane(3)][kh(2)][NP] x 16 B    (weights pre-split by pack_filter_split_kernel)
 // ---------------------------------------------------------------------------------------------
+// NT <= 3: cap VGPRs at 128 so that TWO workgroups share a CU (LDS 2 x 39 KB x 2): with only
+// 36 MFMAs per wave per chunk the DMA latency of a single double-buffered workgroup is exposed.
 template <int NT>
-__global__ __launch_bounds__(512) void conv4tap_x6_kernel(ConvArgs a)
+__global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(ConvArgs a, int ntiles)
 {
     constexpr int NP = NT * 32;
     constexpr int A_STRIDE = 320;
@@ -177,7 +179,6 @@ __global__ __launch_bounds__(512) void conv4tap_x6_kernel(ConvArgs a)
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
-    const long long Q0 = (long long)blockIdx.x * MMLF_TILE;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -189,10 +190,11 @@ __global__ __launch_bounds__(512) void conv4tap_x6_kernel(ConvArgs a)
     const unsigned voff_a = (unsigned)lane * (unsigned)a.cs_in * 4u;   // A pieces: lane = position
     const unsigned voff_b = (unsigned)lane * 16u;                      // B pieces: linear
     const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
-    const char *in_base = reinterpret_cast<const char *>(a.in) + (size_t)Q0 * a.cs_in * 4;
+    const char *in0 = reinterpret_cast<const char *>(a.in);
     const char *wp_base = reinterpret_cast<const char *>(a.wp);
+    const size_t tile_bytes = (size_t)MMLF_TILE * a.cs_in * 4;
 
-#define X6_DMA_PIECE(c, buf, k)                                                                          \
+#define X6_DMA_PIECE(tl, c, buf, k)                                                                      \
     do {                                                                                                 \
         const int j_ = w + 8 * (k);                                                                      \
         if ((k) < PER_WAVE && j_ < N_PIECES) {                                                           \
@@ -200,7 +202,8 @@ __global__ __launch_bounds__(512) void conv4tap_x6_kernel(ConvArgs a)
             unsigned vo_, d_;                                                                            \
             if (j_ < N_A) {                                                                              \
                 const int arr_ = j_ / 5, blk_ = j_ - 5 * arr_;                                           \
-                sb_ = in_base + ((size_t)((arr_ >> 1) * a.P + 64 * blk_) * a.cs_in + 4 * (arr_ & 1) + 8 * (c)) * 4; \
+                sb_ = in0 + (size_t)(tl) * tile_bytes +                                                  \
+                      ((size_t)((arr_ >> 1) * a.P + 64 * blk_) * a.cs_in + 4 * (arr_ & 1) + 8 * (c)) * 4; \
                 vo_ = voff_a;                                                                            \
                 d_ = (unsigned)(arr_ * A_STRIDE + 64 * blk_);                                            \
             } else {                                                                                     \
@@ -215,20 +218,27 @@ __global__ __launch_bounds__(512) void conv4tap_x6_kernel(ConvArgs a)
                          : "=&s"(keep_) : "v"(vo_), "s"(sb_), "s"(d_) : "memory");                      \
         }                                                                                                \
     } while (0)
-#define X6_DMA_SLOT(c, buf, slot)                                                                        \
+#define X6_DMA_SLOT(tl, c, buf, slot)                                                                    \
     do {                                                                                                 \
-        _Pragma("unroll") for (int k_ = 0; k_ < PER_SLOT; ++k_) X6_DMA_PIECE(c, buf, (slot) * PER_SLOT + k_); \
+        _Pragma("unroll") for (int k_ = 0; k_ < PER_SLOT; ++k_)                                          \
+            X6_DMA_PIECE(tl, c, buf, (slot) * PER_SLOT + k_);                                            \
     } while (0)
 #define X6_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-    X6_DMA_SLOT(0, 0, 0);
-    X6_DMA_SLOT(0, 0, 1);
+    // Persistent over tiles: the chunk pipeline runs on across tile boundaries, so the DMA of the next
+    // tile's first chunk is in flight while this tile's last chunk multiplies and its epilogue stores.
+    int tile = blockIdx.x, c = 0;          // chunk being multiplied
+    int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
+    if (tile >= ntiles) return;
+    X6_DMA_SLOT(ntile, nc, 0, 0);
+    X6_DMA_SLOT(ntile, nc, 0, 1);
+    if (++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
     X6_DMA_WAIT();
     __syncthreads();
+    int buf = 0;
 
-    for (int c = 0; c < a.nchunk; ++c) {
-        const int buf = c & 1;
-        const bool more = c + 1 < a.nchunk;
+    while (tile < ntiles) {
+        const bool more = ntile < ntiles;
         const float4 *base = lds + buf * BUF_F4;
         const float4 *ap = base + 32 * w + i + kh;             // + (u*2 + half) * A_STRIDE
         const bf16x8 *bp = reinterpret_cast<const bf16x8 *>(base + A_F4) + kh * NP + i;   // + ((u*3+pl)*2)*NP + 32nt
@@ -270,11 +280,11 @@ __global__ __launch_bounds__(512) void conv4tap_x6_kernel(ConvArgs a)
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
                 if (w < 4) {
-                    if (g == 0) X6_DMA_SLOT(c + 1, buf ^ 1, 0);
-                    if (g == NT) X6_DMA_SLOT(c + 1, buf ^ 1, 1);
+                    if (g == 0) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
+                    if (g == NT) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
                 } else {
-                    if (g == NT / 2) X6_DMA_SLOT(c + 1, buf ^ 1, 0);
-                    if (g == NT + NT / 2) X6_DMA_SLOT(c + 1, buf ^ 1, 1);
+                    if (g == NT / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
+                    if (g == NT + NT / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -287,15 +297,25 @@ __global__ __launch_bounds__(512) void conv4tap_x6_kernel(ConvArgs a)
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][0], bq[g % 3][0], acc[nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
+        if (++c == a.nchunk) {
+            // tile done: epilogue while the next tile's first chunk is landing
+            conv_epilogue<NT>(a, acc, (long long)tile * MMLF_TILE, w, i, kh);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            c = 0;
+            tile += gridDim.x;
+        }
         X6_DMA_WAIT();
         __syncthreads();
+        buf ^= 1;
     }
 #undef X6_DMA_PIECE
 #undef X6_DMA_SLOT
 #undef X6_DMA_WAIT
-    conv_epilogue<NT>(a, acc, Q0, w, i, kh);
 }
-
 
 // 512 threads = 8 waves; tile = 256 positions x NT*32 output channels; wave w owns positions
 // [32w, 32w+32) x all channels (NT accumulator tiles of 32x32).  K is walked in chunks of 8 input
@@ -922,7 +942,18 @@ static int launch_conv_x6(const ConvArgs &a, long long ntiles, hipStream_t st)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv4tap_x6_kernel<NT>, dim3((unsigned)ntiles), dim3(512), lds, st, a);
+    // persistent: one workgroup per CU (two for the narrow variants), each walks tiles b, b+grid, ...
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    long long grid = (long long)cus * (NT <= 3 ? 2 : 1);
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(conv4tap_x6_kernel<NT>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
     return mmlf_launch_status("mmlf_conv2x2_split");
 }
 
