@@ -48,6 +48,7 @@ struct ConvArgs {
     const float *ref;
     long long NQ;
     int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
+    int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6_kernel)
 };
 
 // epilogue shared by the f32 and the split-bf16 kernels: D[row = position][col = channel]; a lane
@@ -163,13 +164,16 @@ template <int NT>
 __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(ConvArgs a, int ntiles)
 {
     constexpr int NP = NT * 32;
-    constexpr int A_STRIDE = 320;
-    constexpr int A_F4 = 4 * A_STRIDE;
+    // A: [channel half(2)][640 slots] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
+    // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
+    // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
+    // instead of 2 x 257.  Otherwise two 320-slot segments (rows y and y+1) are loaded.
+    constexpr int A_HALF = 640;
+    constexpr int A_F4 = 2 * A_HALF;
     constexpr int B_F4 = 12 * NP;
     constexpr int BUF_F4 = A_F4 + B_F4;
-    constexpr int N_A = 20;
-    constexpr int N_PIECES = N_A + B_F4 / 64;
-    constexpr int PER_WAVE = (N_PIECES + 7) / 8;
+    constexpr int N_B = B_F4 / 64;
+    constexpr int PER_WAVE = (20 + N_B + 7) / 8;      // upper bound (two-segment mode: 20 A pieces)
     constexpr int PER_SLOT = (PER_WAVE + 1) / 2;
     constexpr int G = 2 * NT;                   // MFMA groups (6 MFMAs each) per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -193,23 +197,24 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(Con
     const char *in0 = reinterpret_cast<const char *>(a.in);
     const char *wp_base = reinterpret_cast<const char *>(a.wp);
     const size_t tile_bytes = (size_t)MMLF_TILE * a.cs_in * 4;
+    const int n_a = 2 * a.a_pieces, n_pieces = n_a + N_B;
 
 #define X6_DMA_PIECE(tl, c, buf, k)                                                                      \
     do {                                                                                                 \
         const int j_ = w + 8 * (k);                                                                      \
-        if ((k) < PER_WAVE && j_ < N_PIECES) {                                                           \
+        if ((k) < PER_WAVE && j_ < n_pieces) {                                                           \
             const char *sb_;                                                                             \
             unsigned vo_, d_;                                                                            \
-            if (j_ < N_A) {                                                                              \
-                const int arr_ = j_ / 5, blk_ = j_ - 5 * arr_;                                           \
-                sb_ = in0 + (size_t)(tl) * tile_bytes +                                                  \
-                      ((size_t)((arr_ >> 1) * a.P + 64 * blk_) * a.cs_in + 4 * (arr_ & 1) + 8 * (c)) * 4; \
+            if (j_ < n_a) {                                                                              \
+                const int hf_ = j_ >= a.a_pieces, blk_ = j_ - hf_ * a.a_pieces;                          \
+                const int pos_ = 64 * blk_ + (blk_ >= 5 ? a.seg_delta : 0);                              \
+                sb_ = in0 + (size_t)(tl) * tile_bytes + ((size_t)pos_ * a.cs_in + 4 * hf_ + 8 * (c)) * 4; \
                 vo_ = voff_a;                                                                            \
-                d_ = (unsigned)(arr_ * A_STRIDE + 64 * blk_);                                            \
+                d_ = (unsigned)(hf_ * A_HALF + 64 * blk_);                                               \
             } else {                                                                                     \
-                sb_ = wp_base + ((size_t)(c) * B_F4 + 64 * (j_ - N_A)) * 16;                             \
+                sb_ = wp_base + ((size_t)(c) * B_F4 + 64 * (j_ - n_a)) * 16;                             \
                 vo_ = voff_b;                                                                            \
-                d_ = (unsigned)(A_F4 + 64 * (j_ - N_A));                                                 \
+                d_ = (unsigned)(A_F4 + 64 * (j_ - n_a));                                                 \
             }                                                                                            \
             d_ = lds_base + ((buf) * BUF_F4 + d_) * 16u;                                                 \
             unsigned keep_;                                                                              \
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(Con
     while (tile < ntiles) {
         const bool more = ntile < ntiles;
         const float4 *base = lds + buf * BUF_F4;
-        const float4 *ap = base + 32 * w + i + kh;             // + (u*2 + half) * A_STRIDE
+        const float4 *ap = base + 32 * w + i + kh;             // + u * seg_slot + half * A_HALF
         const bf16x8 *bp = reinterpret_cast<const bf16x8 *>(base + A_F4) + kh * NP + i;   // + ((u*3+pl)*2)*NP + 32nt
 
         // raw f32 activations of both K-steps (8 channels of this lane's tap position each)
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(Con
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) ra[u][hf] = ap[(u * 2 + hf) * A_STRIDE];
+            for (int hf = 0; hf < 2; ++hf) ra[u][hf] = ap[u * a.seg_slot + hf * A_HALF];
         bf16x8 bq[3][3];                                       // rotating [slot][plane] weight fragments
 #pragma unroll
         for (int g0 = 0; g0 < 2; ++g0)
@@ -935,7 +940,7 @@ extern "C" int mmlf_pack_filter_split(const float *w, void *packed, int Cout, in
 template <int NT>
 static int launch_conv_x6(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (4 * 320 + 12 * NT * 32) * sizeof(float4);
+    constexpr size_t lds = 2 * (2 * 640 + 12 * NT * 32) * sizeof(float4);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6_kernel<NT>),
@@ -977,6 +982,11 @@ extern "C" int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void 
     a.in = in; a.wp = reinterpret_cast<const float *>(packed); a.bias = bias; a.out = out; a.ref = relu_ref;
     a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
     a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
+    if (g.P + 257 <= 640) {   // one contiguous window of 257 + P positions
+        a.a_pieces = (g.P + 257 + 63) / 64; a.seg_slot = g.P; a.seg_delta = 0;
+    } else {                  // two 320-slot segments: rows y and y+1
+        a.a_pieces = 10; a.seg_slot = 320; a.seg_delta = g.P - 320;
+    }
     const long long ntiles = g.NQpad / MMLF_TILE;
     hipStream_t st = (hipStream_t)stream;
     switch (nt) {
