@@ -198,15 +198,32 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
                                                       float *__restrict__ out, int cs_out, int c_off_out,
                                                       int C_store, int H, int W)
 {
+    // one block per grid row; a thread walks (position, channel group) pairs with stride 256 without
+    // divisions: (x, cg) += (256 / cvn, 256 % cvn) with carry.  Per-channel coefficients sit in LDS.
+    extern __shared__ float coefs[];           // [5][Cpad]: scale, shift, (mean, k1, k2, k3 for MODE 1)
     const int P = W + 2, R = H + 2;
     const int row = blockIdx.x;
     const int y = row % R;
     const size_t base = (size_t)row * P;
     const int cvn = (C_store + V - 1) / V;
+    const int Cpad = cvn * V;
+    for (int c = threadIdx.x; c < Cpad; c += blockDim.x) {
+        const bool ok = c < C;
+        coefs[c] = ok ? scale[c] : 0.f;
+        coefs[Cpad + c] = ok ? shift[c] : 0.f;
+        if (MODE == 1) {
+            coefs[2 * Cpad + c] = ok ? mean[c] : 0.f;
+            coefs[3 * Cpad + c] = ok ? coef[c] : 0.f;
+            coefs[4 * Cpad + c] = ok ? coef[C + c] : 0.f;
+            coefs[5 * Cpad + c] = ok ? coef[2 * C + c] : 0.f;
+        }
+    }
+    __syncthreads();
     const bool row_in = (y >= 1 && y <= H);
-    const int total = P * cvn;
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int x = e / cvn, cg = e - x * cvn;
+    const int dx = 256 / cvn, dc = 256 - dx * cvn;
+    int x = threadIdx.x / cvn, cg = threadIdx.x - x * cvn;
+    for (; x < P; x += dx, cg += dc) {
+        if (cg >= cvn) { cg -= cvn; ++x; if (x >= P) break; }
         float o[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) o[k] = 0.f;
@@ -216,15 +233,13 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
             if (MODE == 1) VecIO<V>::load(gy + (base + x) * cs_gy + c_off_gy + V * cg, gg);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                const int c = V * cg + k;
-                if (c < C) {
-                    const float u = fmaf(zz[k], scale[c], shift[c]);
-                    if (MODE == 0) {
-                        o[k] = fmaxf(u, 0.f);
-                    } else {
-                        const float g = u > 0.f ? gg[k] : 0.f;
-                        o[k] = coef[c] * g - coef[C + c] - coef[2 * C + c] * (zz[k] - mean[c]);
-                    }
+                const int c = V * cg + k;      // channels >= C have zero coefficients -> output 0
+                const float u = fmaf(zz[k], coefs[c], coefs[Cpad + c]);
+                if (MODE == 0) {
+                    o[k] = fmaxf(u, 0.f);
+                } else {
+                    const float g = u > 0.f ? gg[k] : 0.f;
+                    o[k] = coefs[3 * Cpad + c] * g - coefs[4 * Cpad + c] - coefs[5 * Cpad + c] * (zz[k] - coefs[2 * Cpad + c]);
                 }
             }
         }
@@ -585,10 +600,10 @@ extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *
                        c_off + C_store <= cs_y,
                    "mmlf_bn_apply_relu: C=%d cs_z=%d cs_y=%d c_off=%d C_store=%d", C, cs_z, cs_y, c_off, C_store);
     if (cs_y % 4 == 0 && c_off % 4 == 0)
-        hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, z, cs_z,
+        hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
                            nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W);
     else
-        hipLaunchKernelGGL((bn_rows_kernel<0, 2>), dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, z, cs_z,
+        hipLaunchKernelGGL((bn_rows_kernel<0, 2>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
                            nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W);
     return mmlf_launch_status("mmlf_bn_apply_relu");
 }
@@ -624,10 +639,10 @@ extern "C" int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const fl
     MMLF_CHECK_ARG(cs_gy % 2 == 0 && c_off % 2 == 0 && cs_z % 4 == 0 && cs_dz % 4 == 0 && C <= cs_dz,
                    "mmlf_bn_bwd_apply: layout");
     if (cs_gy % 4 == 0 && c_off % 4 == 0)
-        hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, z, cs_z, gy,
+        hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
                            cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W);
     else
-        hipLaunchKernelGGL((bn_rows_kernel<1, 2>), dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, z, cs_z, gy,
+        hipLaunchKernelGGL((bn_rows_kernel<1, 2>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
                            cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W);
     return mmlf_launch_status("mmlf_bn_bwd_apply");
 }
