@@ -69,6 +69,33 @@ def test_conv_forward_and_border(oracle, cin, cout, pad, mode, monkeypatch):
         assert not full.reshape(geo.alloc, cs_out)[geo.NQ:].any()
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('B,H,W', [(1, 3, 400), (1, 1, 1), (2, 2, 700), (5, 96, 96)])
+def test_conv_wide_and_degenerate_frames(oracle, mode, B, H, W, monkeypatch):
+    """Pitch > 383 switches the split kernel to its two-segment activation window; 1x1 images and a
+    batch whose position count is not a tile multiple exercise the ragged ends."""
+    from mmlf_amd import engine
+    monkeypatch.setattr(engine, 'CONV_MODE', mode)
+    dev = _dev()
+    rs = np.random.RandomState(B * 7 + W)
+    cin, cout = 70, 70
+    geo = engine.Geometry(B, H, W)
+    w = rs.uniform(-0.5, 0.5, (cout, cin, 2, 2)).astype(np.float32)
+    b = rs.uniform(-0.5, 0.5, (cout,)).astype(np.float32)
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    for pad in (1, 0):
+        ih, iw, ioff = (H, W, 1) if pad else (H + 1, W + 1, 0)
+        oh, ow, ooff = (H + 1, W + 1, 0) if pad else (H, W, 1)
+        x = rs.uniform(-1, 1, (B, cin, ih, iw)).astype(np.float32)
+        ref = oracle.conv2x2(x, w, b, pad, relu=True)
+        pk = engine.pack_filter(torch.from_numpy(w).to(dev), 0, False)
+        out = torch.zeros(geo.alloc * cs_out, device=dev)
+        engine.conv(geo, torch.from_numpy(grid_from_nchw(x, cs_in, geo, offset=ioff)).to(dev), cs_in, cin, pk,
+                    torch.from_numpy(b).to(dev), cout, out, cs_out, 0 if pad else geo.P + 1, oh, ow, True)
+        got, _ = nchw_from_grid(out.cpu().numpy(), cs_out, cout, geo, oh, ow, ooff)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize('variant', [0, 1, 2])
 def test_filter_variants_equal_image_transforms(oracle, variant):
     """Transposed / transposed+flipped filters on the plain image == plain filters on the
