@@ -1,0 +1,91 @@
+"""Two ranks on ONE MI355X (gloo carries the all-reduce; the compute path is the HIP one):
+exercises the bucket hooks fired from the native backward, the global masked-mean denominator
+and the lock-step of the replicas.  The 8-GPU RCCL run itself is the driver's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import TINY_KW
+from mmlf_amd import synth
+
+pytestmark = pytest.mark.gpu
+B, PS = 4, 16
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _make(seed):
+    from mmlf_amd.feed_forward import FeedForward
+    kw = dict(TINY_KW, model_uncert=True)
+    m = FeedForward(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in
+                       synth.synth_state(synth.param_spec(**kw), seed).items()})
+    return m.to('cuda:0')
+
+
+def _data():
+    stacks, gt, mask = synth.synth_inputs(B, PS, seed=6)
+    mask[0, :, :9] = 0
+    return [torch.from_numpy(s).cuda() for s in stacks], torch.from_numpy(gt).cuda(), torch.from_numpy(mask).cuda()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from mmlf_amd.train import TrainStep
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        step = TrainStep(_make(3 + rank), lr=1e-2, loss_margin=3)
+        assert step.distributed and step.buckets is not None
+        fired = []
+        orig = step.buckets.ready
+        step.buckets.ready = lambda g, key: (fired.append(key), orig(g, key))[1]
+        stacks, gt, mask = _data()
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        losses = [float(step(*[s[lo:hi].contiguous() for s in stacks], gt[lo:hi].contiguous(),
+                             mask[lo:hi].contiguous(), it)) for it in (1, 2)]
+        torch.cuda.synchronize()
+        torch.save({'flat': step.flat.cpu(), 'losses': losses, 'fired': fired}, os.path.join(out_dir, f'r{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_native_path(tmp_path):
+    from mmlf_amd.train import TrainStep
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'r0.pt'), torch.load(tmp_path / 'r1.pt')
+    assert torch.equal(r0['flat'], r1['flat'])
+    # hooks fire in backward order: head block first, shared stream nets last
+    assert r0['fired'][:3] == ['out_net.2', 'out_net.1', 'out_net.0']
+    assert r0['fired'][3:5] == ['in_net_id', 'in_net_hv']
+    # single-process emulation with the same kernels: two replicas, averaged gradients
+    stacks, gt, mask = _data()
+    steps = [TrainStep(_make(3), lr=1e-2, loss_margin=3) for _ in range(2)]
+    margin = steps[0]._mask(mask)
+    total = float(margin.sum())
+    solid = None
+    for it in (1, 2):
+        for r, st in enumerate(steps):
+            st.grad.zero_()
+            den = torch.tensor([total / 2], dtype=torch.float64, device='cuda:0')
+            loss = st._native_fwd_bwd(*[s[2 * r:2 * r + 2].contiguous() for s in stacks], gt[2 * r:2 * r + 2].contiguous(),
+                                      margin[2 * r:2 * r + 2].contiguous(), den)
+            if r == 0:
+                np.testing.assert_allclose(float(loss), r0['losses'][it - 1], rtol=1e-5)
+        avg = (steps[0].grad + steps[1].grad) / 2
+        ok = avg.abs() > 1e-5
+        solid = ok if solid is None else solid & ok
+        for st in steps:
+            st.grad.copy_(avg)
+            st.adam_steps += 1
+            st._adam(st.current_lr(it), 1.0)
+    torch.testing.assert_close(r0['flat'][solid.cpu()], steps[0].flat.cpu()[solid.cpu()], rtol=1e-4, atol=3e-5)
