@@ -150,7 +150,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // forward / data-gradient kernel, split-bf16 arithmetic ("bf16x6"):
 // every f32 operand is split EXACTLY into three bf16 (hi+mid+lo) and each product is evaluated as the
 // six leading cross terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation (dropped terms are
-// <= 2^-26 relative).  Measured on gfx950 (scratch/bf16x6.hip): error vs a double reference
+// <= 2^-26 relative).  Measured on gfx950 (tools/bf16x6_accuracy.hip): error vs a double reference
 // 1.4e-8*sum|a*b| mean, 1.0e-7 max at K=1120 -- slightly BELOW the f32 MFMA fma chain (1.7e-8 /
 // 1.9e-7) -- at 16/6 = 2.67x the f32 MFMA rate.  Same tile shape and LDS-DMA pipeline as
 // conv4tap_kernel; per chunk (8 channels x 4 taps) the K=32 slice is two MFMA K-steps (u = 0,1):
