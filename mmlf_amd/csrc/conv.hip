@@ -8,6 +8,7 @@
 // {0, 1, P, P+1} (include/mmlf_hip.h).  v_mfma_f32_32x32x2_f32 is an exact f32 fma chain, so
 // results are float32-exact up to summation order.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/mmlf_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -120,7 +121,7 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsig
 
 // split-precision filter packing: [chunk][u(2)][plane(3)][kh(2)][NP][8 bf16], tap = 2u+kh, k = 8*chunk+j
 __global__ void pack_filter_split_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Cout,
-                                         int Cin, int variant, int dgrad, int nchunk, int NP)
+                                         int Cin, int variant, int dgrad, int nchunk, int NP, int layout16)
 {
     const long long total = (long long)nchunk * 2 * 2 * NP * 8;   // one thread per (chunk,u,kh,n,j)
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -139,8 +140,11 @@ __global__ void pack_filter_split_kernel(const float *__restrict__ w, unsigned s
         if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 4 + master_tap(tsrc, variant)];
         unsigned p[3];
         split3(v, p[0], p[1], p[2]);
-        for (int pl = 0; pl < 3; ++pl)
-            out[((((size_t)(c * 2 + u) * 3 + pl) * 2 + kh) * NP + n) * 8 + j] = (unsigned short)p[pl];
+        for (int pl = 0; pl < 3; ++pl) {
+            const size_t o = layout16 ? ((((size_t)c * 3 + pl) * 4 + t) * NP + n) * 8 + j       // [chunk][plane][tap][n][8]
+                                      : ((((size_t)(c * 2 + u) * 3 + pl) * 2 + kh) * NP + n) * 8 + j;
+            out[o] = (unsigned short)p[pl];
+        }
     }
 }
 
@@ -310,6 +314,212 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(Con
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            c = 0;
+            tile += gridDim.x;
+        }
+        X6_DMA_WAIT();
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef X6_DMA_PIECE
+#undef X6_DMA_SLOT
+#undef X6_DMA_WAIT
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// epilogue for 16x16 accumulator tiles: lane holds column r16 of each 16-column block and rows
+// 4*q4 + r (r = 0..3) of each 16-position row block.
+template <int G>
+__device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (&acc)[2][G], long long Q0, int w,
+                                                int r16, int q4)
+{
+    unsigned valid = 0;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = (int)Q0 + 32 * w + 16 * mb + 4 * q4 + r;
+            const int rem = q % a.G;
+            const int y = rem / a.P, x = rem - y * a.P;
+            if (q < a.NQ && y < a.vh && x < a.vw) valid |= 1u << (4 * mb + r);
+        }
+#pragma unroll
+    for (int nb = 0; nb < G; ++nb) {
+        const int ch = 16 * nb + r16;
+        if (ch >= a.n_store) continue;
+        const float bv = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long q = Q0 + 32 * w + 16 * mb + 4 * q4 + r + a.out_shift;
+                float v = acc[mb][nb][r] + bv;
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (a.ref) v = (a.ref[(size_t)q * a.cs_ref + ch] > 0.f) ? v : 0.f;
+                v = (valid >> (4 * mb + r) & 1) ? v : 0.f;
+                a.out[(size_t)q * a.cs_out + ch] = v;
+            }
+    }
+}
+
+// 16x16x32-MFMA variant of conv4tap_x6_kernel (K = 32 = the whole 4-tap x 8-channel chunk per MFMA;
+// lane quarter q = lane>>4 carries tap q).  Weight layout [chunk][plane(3)][q(4)][NP][8 bf16].
+// NT <= 3: cap VGPRs at 128 so that TWO workgroups share a CU (LDS 2 x 39 KB x 2): with only
+// 36 MFMAs per wave per chunk the DMA latency of a single double-buffered workgroup is exposed.
+template <int NT>
+__global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
+{
+    constexpr int NP = NT * 32;
+    // A: [channel half(2)][640 slots] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
+    // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
+    // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
+    // instead of 2 x 257.  Otherwise two 320-slot segments (rows y and y+1) are loaded.
+    constexpr int A_HALF = 640;
+    constexpr int A_F4 = 2 * A_HALF;
+    constexpr int B_F4 = 12 * NP;
+    constexpr int BUF_F4 = A_F4 + B_F4;
+    constexpr int N_B = B_F4 / 64;
+    constexpr int PER_WAVE = (20 + N_B + 7) / 8;      // upper bound (two-segment mode: 20 A pieces)
+    constexpr int PER_SLOT = (PER_WAVE + 1) / 2;
+    constexpr int G = 2 * NT;                   // MFMA groups: one 16-column block x 2 row blocks x 6 passes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *lds = reinterpret_cast<float4 *>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q4 = lane >> 4;
+
+    f32x4 acc[2][G];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < G; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
+
+    // DMA addressing: a piece = wave-uniform 64-bit base (SGPRs) + one shared per-lane byte offset
+    const unsigned voff_a = (unsigned)lane * (unsigned)a.cs_in * 4u;   // A pieces: lane = position
+    const unsigned voff_b = (unsigned)lane * 16u;                      // B pieces: linear
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
+    const char *in0 = reinterpret_cast<const char *>(a.in);
+    const char *wp_base = reinterpret_cast<const char *>(a.wp);
+    const size_t tile_bytes = (size_t)MMLF_TILE * a.cs_in * 4;
+    const int n_a = 2 * a.a_pieces, n_pieces = n_a + N_B;
+
+#define X6_DMA_PIECE(tl, c, buf, k)                                                                      \
+    do {                                                                                                 \
+        const int j_ = w + 8 * (k);                                                                      \
+        if ((k) < PER_WAVE && j_ < n_pieces) {                                                           \
+            const char *sb_;                                                                             \
+            unsigned vo_, d_;                                                                            \
+            if (j_ < n_a) {                                                                              \
+                const int hf_ = j_ >= a.a_pieces, blk_ = j_ - hf_ * a.a_pieces;                          \
+                const int pos_ = 64 * blk_ + (blk_ >= 5 ? a.seg_delta : 0);                              \
+                sb_ = in0 + (size_t)(tl) * tile_bytes + ((size_t)pos_ * a.cs_in + 4 * hf_ + 8 * (c)) * 4; \
+                vo_ = voff_a;                                                                            \
+                d_ = (unsigned)(hf_ * A_HALF + 64 * blk_);                                               \
+            } else {                                                                                     \
+                sb_ = wp_base + ((size_t)(c) * B_F4 + 64 * (j_ - n_a)) * 16;                             \
+                vo_ = voff_b;                                                                            \
+                d_ = (unsigned)(A_F4 + 64 * (j_ - n_a));                                                 \
+            }                                                                                            \
+            d_ = lds_base + ((buf) * BUF_F4 + d_) * 16u;                                                 \
+            unsigned keep_;                                                                              \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                       \
+                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"                           \
+                         : "=&s"(keep_) : "v"(vo_), "s"(sb_), "s"(d_) : "memory");                      \
+        }                                                                                                \
+    } while (0)
+#define X6_DMA_SLOT(tl, c, buf, slot)                                                                    \
+    do {                                                                                                 \
+        _Pragma("unroll") for (int k_ = 0; k_ < PER_SLOT; ++k_)                                          \
+            X6_DMA_PIECE(tl, c, buf, (slot) * PER_SLOT + k_);                                            \
+    } while (0)
+#define X6_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+    // Persistent over tiles: the chunk pipeline runs on across tile boundaries, so the DMA of the next
+    // tile's first chunk is in flight while this tile's last chunk multiplies and its epilogue stores.
+    int tile = blockIdx.x, c = 0;          // chunk being multiplied
+    int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
+    if (tile >= ntiles) return;
+    X6_DMA_SLOT(ntile, nc, 0, 0);
+    X6_DMA_SLOT(ntile, nc, 0, 1);
+    if (++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
+    X6_DMA_WAIT();
+    __syncthreads();
+    int buf = 0;
+
+    while (tile < ntiles) {
+        const bool more = ntile < ntiles;
+        const float4 *base = lds + buf * BUF_F4;
+        // lane (r16, q4): row r16 of a 16-position block, tap q4 -> slot offset (q4&1) + (q4>>1)*seg_slot
+        const float4 *ap = base + 32 * w + r16 + (q4 & 1) + (q4 >> 1) * a.seg_slot;   // + 16*mb + half*A_HALF
+        const bf16x8 *bp = reinterpret_cast<const bf16x8 *>(base + A_F4) + q4 * NP + r16;   // + pl*4*NP + 16*nb
+
+        float4 ra[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) ra[mb][hf] = ap[16 * mb + hf * A_HALF];
+        bf16x8 bq[3][3];                                       // rotating [slot][plane] weight fragments
+#pragma unroll
+        for (int g0 = 0; g0 < 2; ++g0)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bq[g0][pl] = bp[pl * 4 * NP + 16 * g0];
+        bf16x8 asp[2][3];                                      // [row block][plane] split activations
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            unsigned hh[4], mm[4], ll[4];
+            split3_pair(ra[mb][0].x, ra[mb][0].y, hh[0], mm[0], ll[0]);
+            split3_pair(ra[mb][0].z, ra[mb][0].w, hh[1], mm[1], ll[1]);
+            split3_pair(ra[mb][1].x, ra[mb][1].y, hh[2], mm[2], ll[2]);
+            split3_pair(ra[mb][1].z, ra[mb][1].w, hh[3], mm[3], ll[3]);
+            const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vm = {mm[0], mm[1], mm[2], mm[3]},
+                          vl = {ll[0], ll[1], ll[2], ll[3]};
+            asp[mb][0] = __builtin_bit_cast(bf16x8, vh);
+            asp[mb][1] = __builtin_bit_cast(bf16x8, vm);
+            asp[mb][2] = __builtin_bit_cast(bf16x8, vl);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g + 2 < G) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bq[(g + 2) % 3][pl] = bp[pl * 4 * NP + 16 * (g + 2)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                if (w < 4) {
+                    if (g == 0) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
+                    if (g == NT) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
+                } else {
+                    if (g == NT / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
+                    if (g == NT + NT / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][2], bq[g % 3][0], acc[mb][g], 0, 0, 0);
+                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][0], bq[g % 3][2], acc[mb][g], 0, 0, 0);
+                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][1], bq[g % 3][1], acc[mb][g], 0, 0, 0);
+                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][1], bq[g % 3][0], acc[mb][g], 0, 0, 0);
+                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][0], bq[g % 3][1], acc[mb][g], 0, 0, 0);
+                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][0], bq[g % 3][0], acc[mb][g], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
+        if (++c == a.nchunk) {
+            // tile done: epilogue while the next tile's first chunk is landing
+            conv_epilogue16<G>(a, acc, (long long)tile * MMLF_TILE, w, r16, q4);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < G; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
             c = 0;
             tile += gridDim.x;
         }
@@ -913,6 +1123,10 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
 }
 
 // ------------------------------------------------------------------ split-bf16 ("bf16x6") entry points
+// narrow layers (N <= 96) run the 16x16x32-MFMA variant (measured ~10 % faster there; the 32x32x16
+// variant wins at N = 288).  Packing and launch pick by the same rule, so the layouts always agree.
+static inline int x6_shape16(int nt) { return nt <= 3; }
+
 extern "C" int64_t mmlf_packed_filter_split_bytes(int K, int N)
 {
     const int nt = pick_nt(N);
@@ -933,7 +1147,7 @@ extern "C" int mmlf_pack_filter_split(const float *w, void *packed, int Cout, in
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_filter_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                       (unsigned short *)packed, Cout, Cin, variant, dgrad, nchunk, NP);
+                       (unsigned short *)packed, Cout, Cin, variant, dgrad, nchunk, NP, x6_shape16(nt));
     return mmlf_launch_status("mmlf_pack_filter_split");
 }
 
@@ -958,7 +1172,17 @@ static int launch_conv_x6(const ConvArgs &a, long long ntiles, hipStream_t st)
     }
     long long grid = (long long)cus * (NT <= 3 ? 2 : 1);
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(conv4tap_x6_kernel<NT>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
+    if (x6_shape16(NT)) {
+        static bool attr16 = false;
+        if (!attr16) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<NT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr16 = true;
+        }
+        hipLaunchKernelGGL(conv4tap_x6s_kernel<NT>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
+    } else {
+        hipLaunchKernelGGL(conv4tap_x6_kernel<NT>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
+    }
     return mmlf_launch_status("mmlf_conv2x2_split");
 }
 
