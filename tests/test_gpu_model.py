@@ -167,3 +167,37 @@ def test_halo_11_tile_invariance_eval():
         crop = m(*[t[..., 8:56, 8:56].contiguous() for t in ts])['mean']
     np.testing.assert_allclose(crop[:, 11:-11, 11:-11].cpu().numpy(), full[:, 19:45, 19:45].cpu().numpy(),
                                rtol=1e-5, atol=1e-6)
+
+
+def test_reference_train_loop_shape_dataparallel_adam_autograd():
+    """The reference's own loop body (train/cli.py:159,243-258): DataParallel wrap, torch.optim.Adam,
+    loss.backward() through autograd -- must give the same update as the native TrainStep."""
+    from mmlf_amd import loss
+    from mmlf_amd.train import TrainStep
+    g = load_golden('g1_tiny_upr.npz')
+    kw = dict(TINY_KW, model_uncert=True)
+    dev = _dev()
+    stacks = [torch.from_numpy(g[f'in{i}']).to(dev) for i in range(4)]
+    gt, mask = torch.from_numpy(g['gt']).to(dev), torch.from_numpy(g['mask']).to(dev)
+    m1 = _model(kw, _state(g))
+    dp = torch.nn.DataParallel(m1)
+    opt = torch.optim.Adam(dp.parameters(), lr=1e-3)
+    dp.train()
+    opt.zero_grad()
+    out = dp(*stacks)
+    l1 = loss.ImprovedUncertaintyL1Loss()(out, gt, mask, None)
+    l1.backward()
+    opt.step()
+    m2 = _model(kw, _state(g))
+    st = TrainStep(m2, lr=1e-3, loss_margin=0)
+    l2 = st(*stacks, gt, mask, 1)
+    np.testing.assert_allclose(float(l1), float(l2), rtol=1e-6)
+    np.testing.assert_allclose(float(l1), g['loss'], rtol=2e-5)
+    for (k, a), (_, b) in zip(dp.module.state_dict().items(), m2.state_dict().items()):
+        ref_g = g.get(f'grad/{k}')
+        if ref_g is not None:      # compare where the gradient is far above rounding noise
+            solid = torch.from_numpy(np.abs(ref_g) > 1e-5)
+            torch.testing.assert_close(a.cpu()[solid], b.cpu()[solid], rtol=0, atol=3e-6, msg=k)
+            np.testing.assert_allclose(a.cpu().numpy()[solid.numpy()], g[f'post/{k}'][solid.numpy()], rtol=0, atol=3e-6, err_msg=k)
+        else:
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=k)
