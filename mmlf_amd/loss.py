@@ -136,3 +136,30 @@ class MaskedCrossEntropy(nn.Module):
         s = F.relu(input['scores'])
         loss = -torch.log(torch.exp(torch.sum(s * target, 1)) / torch.sum(torch.exp(s), 1))
         return _masked_mean(loss, mask)
+
+
+# ------------------------------------------------------------------ multimodal training losses
+# (reached with --train_loss_multimodal, reference train/cli.py:120-123,224-225).
+# `target` is the multi-plane tensor (B, P, 5, H, W): channel 3 = alpha, channel 4 = disparity.
+class MultiMaskedL1Loss(nn.Module):
+    """loss.py:80-103: alpha-weighted L1 to every plane, masked mean."""
+
+    def forward(self, input, target, mask):
+        weights, targets = target[:, :, 3], target[:, :, 4]
+        diff = (torch.abs(input['mean'].unsqueeze(1) - targets) * weights).sum(1)
+        return _masked_mean(diff, mask)
+
+
+class ImprovedMultiUncertaintyL1Loss(nn.Module):
+    """loss.py:336-372: alpha-weighted Laplace NLL normalised by the mean total alpha, plus a
+    -logvar term on pixels without any surface (total alpha < 0.01), each side rescaled; masked mean."""
+
+    def forward(self, input, target, mask, mask_padding=None):
+        weights, targets = target[:, :, 3], target[:, :, 4]
+        mean, logvar = input['mean'], input['logvar']
+        loss = torch.exp(-logvar).unsqueeze(1) * torch.abs(mean.unsqueeze(1) - targets) + logvar.unsqueeze(1)
+        total = weights.sum(1)
+        loss = (loss * weights).sum(1) / torch.mean(total)
+        oor = (total < 0.01).float()
+        loss_oor = -logvar * oor * (oor.numel() / torch.sum(oor))
+        return _masked_mean((loss + loss_oor) / 2.0, mask)

@@ -1,0 +1,76 @@
+"""Validate-side distribution metrics: counterparts of the numpy helpers
+in reference mmlf/validate/cli.py:17-187, as torch expressions that run on the device the model
+outputs already live on (float64, like numpy's promotion in the reference), so the 70-component
+maps of the ensemble never travel to the host."""
+import torch
+
+
+def _f64(x):
+    return x.double()
+
+
+def cdf_laplace(disp, mean, var):
+    """validate/cli.py:74-87"""
+    le = disp < mean
+    res_le = torch.exp((disp - mean) / var) / 2
+    res_ge = 1 - torch.exp(-(disp - mean) / var) / 2
+    return torch.where(le, res_le, res_ge)
+
+
+def laplace_to_discrete(n_bins, x_min, x_max, mean, logvar):
+    """validate/cli.py:90-103: probability mass of Laplace(mean, exp(logvar)) in each of n_bins bins.
+    The reference computes in numpy float32 x float64 -> float64; exp(logvar) stays float32."""
+    step = (x_max - x_min) / n_bins
+    edges = torch.linspace(x_min - step / 2.0, x_max + step / 2.0, n_bins + 1, dtype=torch.float64,
+                           device=mean.device).view(1, -1, 1, 1)
+    mean = _f64(mean).unsqueeze(1)
+    var = _f64(torch.exp(logvar)).unsqueeze(1)
+    cdf = cdf_laplace(edges, mean, var)
+    return cdf[:, 1:] - cdf[:, :-1]
+
+
+def lmm_to_discrete(n_bins, x_min, x_max, means, logvars):
+    """validate/cli.py:106-118: mean of the members' discretised Laplacians.  NOTE the reference's
+    caller passes exp(logvars) under the name `logvars` (validate/cli.py:302,318); mirror that."""
+    out = torch.zeros((means.shape[1], n_bins, means.shape[2], means.shape[3]), dtype=torch.float64,
+                      device=means.device)
+    for i in range(means.shape[0]):
+        out += laplace_to_discrete(n_bins, x_min, x_max, means[i], logvars[i])
+    return out / means.shape[0]
+
+
+def mean_to_discrete(n_bins, x_min, x_max, mean):
+    """validate/cli.py:121-138"""
+    step = (x_max - x_min) / n_bins
+    centres = torch.linspace(x_min, x_max, n_bins, dtype=torch.float64, device=mean.device).view(1, -1, 1, 1)
+    return (torch.abs(centres - _f64(mean).unsqueeze(1)) < step / 2.0).double()
+
+
+def multimodal_mask(mpi, threshhold=0.3):
+    """validate/cli.py:166-171"""
+    return ((mpi[:, :, 3] > threshhold).sum(1) > 1).double()
+
+
+def kl_divergence(dist, dist_gt, mask=None):
+    """validate/cli.py:174-187 (batch size 1, as in validate).  Does not modify its inputs."""
+    eps = 0.00001
+    dist = dist + eps
+    dist_gt = dist_gt + eps
+    dist = dist / dist.sum(1, keepdim=True)
+    dist_gt = dist_gt / dist_gt.sum(1, keepdim=True)
+    kld = (dist_gt * torch.log(dist_gt / dist)).sum(1)
+    if mask is None:
+        return kld.mean()
+    return (kld * mask).sum() / mask.sum()
+
+
+def nll_laplace(mpi, mean, logvar, mask=None):
+    """validate/cli.py:26-49"""
+    disp, alpha = mpi[:, :, 4], mpi[:, :, 3]
+    mean = mean.unsqueeze(1)
+    var = torch.exp(logvar.unsqueeze(1))
+    prob = torch.exp(-(torch.abs(mean - disp)) / var) / var / 2.0 + 0.00001
+    nllh = (alpha * -torch.log(prob)).sum(1)
+    if mask is not None:
+        return (nllh * mask).sum() / mask.sum()
+    return nllh.mean()

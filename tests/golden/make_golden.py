@@ -250,11 +250,62 @@ def g5_losses():
     print('G5 ok', len(rec))
 
 
+def g6_multimodal():
+    """multimodal targets and losses (loss.py:80-103,336-372; dl.py:134-157)."""
+    rs = np.random.RandomState(6)
+    B, P, H, W = 2, 3, 14, 18
+    mpi = rs.uniform(size=(B, P, 5, H, W)).astype(np.float32)
+    mpi[:, :, 4] = (7.4 * rs.uniform(size=(B, P, H, W)) - 3.7).astype(np.float32)
+    wts = rs.uniform(size=(B, P, H, W)).astype(np.float32)
+    wts[rs.uniform(size=wts.shape) < 0.35] = 0.0
+    wts[:, :, :3, :4] = 0.0                     # out-of-range pixels: no surface at all
+    mpi[:, :, 3] = wts
+    mean = (mpi[:, 0, 4] + rs.normal(scale=0.2, size=(B, H, W))).astype(np.float32)
+    logvar = rs.normal(scale=0.5, size=(B, H, W)).astype(np.float32)
+    mask = (rs.uniform(size=(B, H, W)) > 0.25).astype(np.int32)
+    rec = dict(mpi=mpi, mean=mean, logvar=logvar, mask=mask)
+    tm, tl, tmpi, tmask = map(torch.from_numpy, (mean, logvar, mpi, mask))
+    rec['mpi_to_weights'] = ref_dl.mpi_to_weights(tmpi, -3.5, 3.5, 108).numpy()
+    for name, fn, keys in (('multi_l1', ref_loss.MultiMaskedL1Loss(), ['mean']),
+                           ('multi_upr', ref_loss.ImprovedMultiUncertaintyL1Loss(), ['mean', 'logvar'])):
+        o = {'mean': tm.clone().requires_grad_(True), 'logvar': tl.clone().requires_grad_(True)}
+        val = fn(o, tmpi, tmask)
+        val.backward()
+        rec[name] = val.detach().numpy()
+        for k in keys:
+            rec[f'd{name}_d{k}'] = o[k].grad.numpy()
+    # validate-side metric inputs/outputs (row f2), numpy like the reference; the reference's
+    # kl_divergence only broadcasts for batch size 1 (validate/cli.py:179), which is what validate uses
+    from mmlf.validate import cli as vcli
+    mpi1, mean1, logvar1 = mpi[:1], mean[:1], logvar[:1]
+    rec['multimodal_mask'] = vcli.multimodal_mask(mpi1)
+    rec['laplace_to_discrete'] = vcli.laplace_to_discrete(108, -3.5, 3.5, mean1, logvar1)
+    means = np.stack([mean1 + 0.1 * k for k in range(5)]).astype(np.float32)
+    logvars = np.stack([logvar1 - 0.05 * k for k in range(5)]).astype(np.float32)
+    rec['lmm_means'], rec['lmm_logvars'] = means, logvars
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        # validate/cli.py:302,318 passes exp(logvars) under the name `logvars`; mirror the call
+        rec['lmm_to_discrete'] = vcli.lmm_to_discrete(108, -3.5, 3.5, means, np.exp(logvars))
+        dist_gt = ref_dl.mpi_to_weights(torch.from_numpy(mpi1), -3.5, 3.5, 108).numpy()
+        rec['kld'] = vcli.kl_divergence(rec['laplace_to_discrete'].copy(), dist_gt.copy())
+        rec['kld_masked'] = vcli.kl_divergence(rec['laplace_to_discrete'].copy(), dist_gt.copy(),
+                                               rec['multimodal_mask'])
+        rec['nll_laplace'] = vcli.nll_laplace(mpi1, mean1, logvar1, None)
+        rec['mean_to_discrete'] = vcli.mean_to_discrete(108, -3.5, 3.5, mean1)
+    np.savez_compressed(os.path.join(HERE, 'g6_multimodal.npz'), **rec)
+    print('G6 ok', {k: np.asarray(v).shape for k, v in rec.items()})
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'g6':
+        g6_multimodal()
+        sys.exit(0)
     g1_tiny()
     g4_shift_ensamble()
     g5_losses()
     g2_full()
+    g6_multimodal()
     sizes = {f: os.path.getsize(os.path.join(HERE, f)) for f in sorted(os.listdir(HERE))
              if f.endswith('.npz')}
     print(sizes)

@@ -1,0 +1,88 @@
+"""SURVEY section 8 'next' rows: f4 multimodal targets/losses, f3 checkpoint format / resume,
+f2 validate-side distribution metrics -- against goldens generated from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TINY_KW, load_golden
+from mmlf_amd import dl, loss, metrics, synth
+from mmlf_amd.feed_forward import FeedForward
+from mmlf_amd.train import TrainStep
+
+DEVICES = ['cpu', pytest.param('cuda', marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize('dev', DEVICES)
+def test_multimodal_targets_and_losses(dev):
+    g = load_golden('g6_multimodal.npz')
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    np.testing.assert_allclose(dl.mpi_to_weights(t('mpi'), -3.5, 3.5, 108).cpu().numpy(), g['mpi_to_weights'],
+                               rtol=1e-6, atol=1e-7)
+    for name, fn, keys in (('multi_l1', loss.MultiMaskedL1Loss(), ['mean']),
+                           ('multi_upr', loss.ImprovedMultiUncertaintyL1Loss(), ['mean', 'logvar'])):
+        o = {'mean': t('mean').requires_grad_(True), 'logvar': t('logvar').requires_grad_(True)}
+        val = fn(o, t('mpi'), t('mask'))
+        val.backward()
+        np.testing.assert_allclose(val.item(), g[name], rtol=2e-6)
+        for k in keys:
+            np.testing.assert_allclose(o[k].grad.cpu().numpy(), g[f'd{name}_d{k}'], rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('dev', DEVICES)
+def test_validate_distribution_metrics(dev):
+    g = load_golden('g6_multimodal.npz')
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    mean, logvar, mpi = t('mean')[:1], t('logvar')[:1], t('mpi')[:1]
+    l2d = metrics.laplace_to_discrete(108, -3.5, 3.5, mean, logvar)
+    np.testing.assert_allclose(l2d.cpu().numpy(), g['laplace_to_discrete'], rtol=1e-6, atol=1e-12)
+    lmm = metrics.lmm_to_discrete(108, -3.5, 3.5, t('lmm_means'), torch.exp(t('lmm_logvars')))
+    np.testing.assert_allclose(lmm.cpu().numpy(), g['lmm_to_discrete'], rtol=1e-6, atol=1e-12)
+    np.testing.assert_array_equal(metrics.mean_to_discrete(108, -3.5, 3.5, mean).cpu().numpy(), g['mean_to_discrete'])
+    mm = metrics.multimodal_mask(mpi)
+    np.testing.assert_array_equal(mm.cpu().numpy(), g['multimodal_mask'])
+    gt = dl.mpi_to_weights(mpi, -3.5, 3.5, 108)      # float32 like the reference's dist_gt
+    np.testing.assert_allclose(metrics.kl_divergence(l2d, gt).item(), g['kld'], rtol=1e-6)
+    np.testing.assert_allclose(metrics.kl_divergence(l2d, gt, mm).item(), g['kld_masked'], rtol=1e-6)
+    np.testing.assert_allclose(metrics.nll_laplace(mpi, mean, logvar).item(), g['nll_laplace'], rtol=1e-5)
+
+
+def test_checkpoint_format_and_resume(tmp_path):
+    """f3: the file ModelSaver writes has the reference's keys, loads into torch.optim.Adam, and a
+    resumed TrainStep continues exactly like an uninterrupted one."""
+    kw = dict(TINY_KW, train_lr=1e-3, model_radius=5)
+    state = synth.synth_state(synth.param_spec(**TINY_KW), 4)
+
+    def fresh():
+        m = FeedForward(**kw)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        return m
+
+    stacks, gt, mask = synth.synth_inputs(2, 16, seed=2)
+    data = [torch.from_numpy(s) for s in stacks] + [torch.from_numpy(gt), torch.from_numpy(mask)]
+    a = TrainStep(fresh(), lr=1e-3, loss_margin=3)
+    for it in (1, 2):
+        a(*data, it)
+    path = str(tmp_path / 'checkpoint.pt')
+    dl.ModelSaver(only_best=False)(path, a.model, a, kw, None, 2, 0.5)
+    ck = torch.load(path)
+    assert set(ck) == {'model_state_dict', 'optimizer_state_dict', 'hyper_parameters', 'epoch', 'iteration', 'loss'}
+    assert ck['iteration'] == 2 and ck['epoch'] is None and ck['hyper_parameters']['model_radius'] == 5
+    assert list(ck['model_state_dict']) == list(fresh().state_dict())
+    # the optimizer part is a valid torch.optim.Adam state dict
+    m = fresh()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-5)
+    it, _ = dl.load_checkpoint(path, m, opt, lr=1e-3)
+    assert it == 2 and opt.param_groups[0]['lr'] == 1e-3
+    assert float(opt.state_dict()['state'][0]['step']) == 2.0
+    # resume == continue
+    b = TrainStep(fresh(), lr=1e-5, loss_margin=3)
+    it, _ = dl.load_checkpoint(path, b.model, b, lr=1e-3)
+    a(*data, 3)
+    b(*data, 3)
+    for (k, va), (_, vb) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        torch.testing.assert_close(va, vb, rtol=0, atol=0, msg=k)
+    # only_best keeps the better checkpoint
+    saver = dl.ModelSaver(only_best=True)
+    saver(path, a.model, None, kw, None, 3, 0.4)
+    saver(path, a.model, None, kw, None, 4, 0.9)
+    assert torch.load(path)['iteration'] == 3
