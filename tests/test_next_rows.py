@@ -41,8 +41,8 @@ def test_validate_distribution_metrics(dev):
     mm = metrics.multimodal_mask(mpi)
     np.testing.assert_array_equal(mm.cpu().numpy(), g['multimodal_mask'])
     gt = dl.mpi_to_weights(mpi, -3.5, 3.5, 108)      # float32 like the reference's dist_gt
-    np.testing.assert_allclose(metrics.kl_divergence(l2d, gt).item(), g['kld'], rtol=1e-6)
-    np.testing.assert_allclose(metrics.kl_divergence(l2d, gt, mm).item(), g['kld_masked'], rtol=1e-6)
+    np.testing.assert_allclose(metrics.kl_divergence(l2d, gt).item(), g['kld'], rtol=1e-5)   # dist_gt is float32 in the reference
+    np.testing.assert_allclose(metrics.kl_divergence(l2d, gt, mm).item(), g['kld_masked'], rtol=1e-5)
     np.testing.assert_allclose(metrics.nll_laplace(mpi, mean, logvar).item(), g['nll_laplace'], rtol=1e-5)
 
 
