@@ -72,11 +72,13 @@ class GradBuckets:
 
 class TrainStep:
     def __init__(self, model, lr, variant=None, warm_start=False, cooling=0, betas=(0.9, 0.999), eps=1e-8,
-                 loss_margin=11, process_group=None):
+                 loss_margin=11, process_group=None, loss_multimodal=False, loss_padding=None):
         self.model = model
         self.lr, self.warm_start, self.cooling = float(lr), bool(warm_start), int(cooling)
         self.betas, self.eps, self.margin = betas, float(eps), int(loss_margin)
         self.variant = variant or ('upr' if model.uncert else ('dpp' if model.discrete else 'base'))
+        # --train_loss_multimodal: `gt` is the multi-plane tensor (B,P,5,H,W) (train/cli.py:120-123,201-225)
+        self.multimodal, self.loss_padding = bool(loss_multimodal), loss_padding
         self.flat, self.layout = flatten_parameters(model)
         self.grad = torch.zeros_like(self.flat)
         self.exp_avg = torch.zeros_like(self.flat)
@@ -145,22 +147,52 @@ class TrainStep:
         p = model._tensor_dict()
         with torch.no_grad():
             out, tape = model._trunk.forward(p, [h, v, i_, d], True, True)
-            kind = KINDS[self.variant]
-            grid, half = None, 0.0
-            if kind == loss_mod.KIND_CE:
-                grid = model._grid('torch', out.device)
-                half = (model.disp_max - model.disp_min) / model.steps / 2.0
-            loss, gout = loss_mod.native_loss(kind, out, gt, mask, grid, half, True, den)
+            if self.multimodal:
+                loss, gout = self._multimodal_loss(out, gt, mask, den)
+            else:
+                kind = KINDS[self.variant]
+                grid, half = None, 0.0
+                if kind == loss_mod.KIND_CE:
+                    grid = model._grid('torch', out.device)
+                    half = (model.disp_max - model.disp_min) / model.steps / 2.0
+                loss, gout = loss_mod.native_loss(kind, out, gt, mask, grid, half, True, den)
             on_done = (lambda key: self.buckets.ready(self.grad, key)) if self.distributed else None
             model._trunk.backward(p, tape, gout, self._grads, on_done)
         return loss
+
+    def _multimodal_heads_loss(self, heads, mpi, mask):
+        model = self.model
+        if self.loss_padding is not None:                       # train/cli.py:219-220
+            mpi = mpi.clone()
+            mpi[:, :, 3] *= (torch.abs(mpi[:, :, 4]) < self.loss_padding).float()
+        if self.variant == 'upr':
+            return loss_mod.ImprovedMultiUncertaintyL1Loss()(heads, mpi, mask)
+        if self.variant == 'dpp':
+            tgt = dl.mpi_to_weights(mpi, model.disp_min, model.disp_max, model.steps)
+            return loss_mod.MaskedCrossEntropy()(heads, tgt, mask)
+        return loss_mod.MultiMaskedL1Loss()(heads, mpi, mask)
+
+    def _multimodal_loss(self, out, mpi, mask, den):
+        """Multimodal losses are small elementwise expressions over (B,P,H,W): evaluated with torch
+        ops and differentiated w.r.t. the raw trunk output, which feeds the native backward."""
+        with torch.enable_grad():
+            o = out.detach().requires_grad_(True)
+            heads = {'mean': o[:, 0], 'logvar': o[:, 1] if self.variant == 'upr' else None, 'scores': o}
+            loss = self._multimodal_heads_loss(heads, mpi, mask)
+            if den is not None:
+                cnt = mask.sum().double()
+                loss = loss * (cnt / den.squeeze()).float() if cnt > 0 else loss
+            (gout,) = torch.autograd.grad(loss, o)
+        return loss.detach(), gout.contiguous()
 
     def _torch_fwd_bwd(self, h, v, i_, d, gt, mask, den):
         model = self.model
         for _, p in model.named_parameters():
             p.grad = None
         out = model(h, v, i_, d)
-        if self.variant == 'upr':
+        if self.multimodal:
+            loss = self._multimodal_heads_loss(out, gt, mask)
+        elif self.variant == 'upr':
             loss = loss_mod.ImprovedUncertaintyL1Loss()(out, gt, mask, None)
         elif self.variant == 'dpp':
             tgt = dl.reg_to_class(gt, model.disp_min, model.disp_max, model.steps)

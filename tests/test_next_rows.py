@@ -86,3 +86,33 @@ def test_checkpoint_format_and_resume(tmp_path):
     saver(path, a.model, None, kw, None, 3, 0.4)
     saver(path, a.model, None, kw, None, 4, 0.9)
     assert torch.load(path)['iteration'] == 3
+
+
+@pytest.mark.parametrize('dev', DEVICES)
+@pytest.mark.parametrize('variant', ['base', 'upr'])
+def test_multimodal_train_step(dev, variant):
+    """--train_loss_multimodal through TrainStep equals the same loss through plain autograd."""
+    g = load_golden('g6_multimodal.npz')
+    kw = dict(TINY_KW, model_uncert=(variant == 'upr'))
+    state = synth.synth_state(synth.param_spec(**kw), 9)
+
+    def fresh():
+        m = FeedForward(**kw)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        return m.to(dev)
+
+    stacks, _, _ = synth.synth_inputs(2, 14, seed=3, ps_w=18)
+    data = [torch.from_numpy(s).to(dev) for s in stacks]
+    mpi, mask = torch.from_numpy(g['mpi']).to(dev), torch.from_numpy(g['mask']).to(dev)
+    st = TrainStep(fresh(), lr=1e-3, loss_margin=2, loss_multimodal=True)
+    l1 = st(*data, mpi, mask, 1)
+    m2 = fresh()
+    m2.train()
+    fn = loss.ImprovedMultiUncertaintyL1Loss() if variant == 'upr' else loss.MultiMaskedL1Loss()
+    l2 = fn(m2(*data), mpi, st._mask(mask))
+    np.testing.assert_allclose(float(l1), float(l2.detach()), rtol=1e-5)
+    l2.backward()
+    for (n, o, cnt), (_, p) in zip(st.layout, m2.named_parameters()):
+        ref = p.grad.reshape(-1).cpu()
+        got = st.grad[o:o + cnt].cpu()
+        assert float((got - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-6, n
