@@ -236,7 +236,13 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(Con
 
     // Persistent over tiles: the chunk pipeline runs on across tile boundaries, so the DMA of the next
     // tile's first chunk is in flight while this tile's last chunk multiplies and its epilogue stores.
-    int tile = blockIdx.x, c = 0;          // chunk being multiplied
+    // XCD-aware tile order: blocks b and b+8 share an XCD (one L2).  Give every XCD a CONTIGUOUS run of
+    // tiles per sweep so that the halo rows two neighbouring tiles both read are served by one L2
+    // (speed only: any placement computes the same result).
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int first_tile = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3)
+                                                : (int)blockIdx.x;
+    int tile = first_tile, c = 0;          // chunk being multiplied
     int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
     if (tile >= ntiles) return;
     X6_DMA_SLOT(ntile, nc, 0, 0);
@@ -441,7 +447,13 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6s_kernel(Co
 
     // Persistent over tiles: the chunk pipeline runs on across tile boundaries, so the DMA of the next
     // tile's first chunk is in flight while this tile's last chunk multiplies and its epilogue stores.
-    int tile = blockIdx.x, c = 0;          // chunk being multiplied
+    // XCD-aware tile order: blocks b and b+8 share an XCD (one L2).  Give every XCD a CONTIGUOUS run of
+    // tiles per sweep so that the halo rows two neighbouring tiles both read are served by one L2
+    // (speed only: any placement computes the same result).
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int first_tile = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3)
+                                                : (int)blockIdx.x;
+    int tile = first_tile, c = 0;          // chunk being multiplied
     int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
     if (tile >= ntiles) return;
     X6_DMA_SLOT(ntile, nc, 0, 0);
