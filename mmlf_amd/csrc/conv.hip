@@ -739,10 +739,6 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_kernel(WgradArgs a)
                 const int ch = ci0 + 4 * f;
                 if (ch < a.cs_in)
                     v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch);
-                if (ch == a.cin) v.x = 1.f;
-                if (ch + 1 == a.cin) v.y = 1.f;
-                if (ch + 2 == a.cin) v.z = 1.f;
-                if (ch + 3 == a.cin) v.w = 1.f;
             }
             ra[j] = v;
         }
@@ -760,7 +756,15 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_kernel(WgradArgs a)
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int idx = tid + 256 * j;
-            if (idx < 528) reinterpret_cast<float4 *>(As)[idx] = ra[j];
+            if (idx < 528) {
+                float4 v = ra[j];          // ones row (bias gradient) patched at store time
+                const int ch = ci0 + 4 * (idx & 7);
+                if (ch == a.cin) v.x = 1.f;
+                if (ch + 1 == a.cin) v.y = 1.f;
+                if (ch + 2 == a.cin) v.z = 1.f;
+                if (ch + 3 == a.cin) v.w = 1.f;
+                reinterpret_cast<float4 *>(As)[idx] = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NG; ++j) reinterpret_cast<float4 *>(Gs)[tid + 256 * j] = rg[j];
@@ -873,10 +877,6 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6_kernel(WgradArgs a)
                 const int ch = ci0 + 4 * f;                                                                 \
                 if (ch < a.cs_in)                                                                           \
                     v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
-                if (ch == a.cin) v.x = 1.f;                                                                 \
-                if (ch + 1 == a.cin) v.y = 1.f;                                                             \
-                if (ch + 2 == a.cin) v.z = 1.f;                                                             \
-                if (ch + 3 == a.cin) v.w = 1.f;                                                             \
             }                                                                                               \
             ra[j] = v;                                                                                      \
         }                                                                                                   \
@@ -896,7 +896,13 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6_kernel(WgradArgs a)
             if (idx < 528) {                                                                                \
                 const int row = idx >> 3, f = idx & 7;                                                      \
                 const int seg = row >= 33, pix = row - 33 * seg;                                            \
-                split_store4(ra[j], As + seg * 3 * A_PLANE + pix * A_ROW + 8 * f, A_PLANE);                 \
+                float4 v = ra[j];         /* ones row (bias gradient): patched here, not at load time, */ \
+                const int ch = ci0 + 4 * f; /* so that the global loads issue back to back               */ \
+                if (ch == a.cin) v.x = 1.f;                                                                 \
+                if (ch + 1 == a.cin) v.y = 1.f;                                                             \
+                if (ch + 2 == a.cin) v.z = 1.f;                                                             \
+                if (ch + 3 == a.cin) v.w = 1.f;                                                             \
+                split_store4(v, As + seg * 3 * A_PLANE + pix * A_ROW + 8 * f, A_PLANE);                     \
             }                                                                                               \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
