@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--global-batch', type=int, default=512)
     ap.add_argument('--patch', type=int, default=96)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-f32-leg', action='store_true', help='skip the extra exact-f32-MFMA measurement')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -139,6 +140,26 @@ def main():
     sync()
     dt = time.time() - t0
     prof, engine.PROFILE = engine.PROFILE, None
+    # second leg (N=1 only): the same step on the exact-f32 MFMA kernels, for comparison
+    f32_leg = None
+    if world == 1 and not args.no_f32_leg and engine.CONV_MODE != 'f32':
+        mode = engine.CONV_MODE
+        engine.CONV_MODE = 'f32'
+        step(*stacks, gt, mask, it)
+        sync()
+        engine.PROFILE = []
+        t1 = time.time()
+        for _ in range(2):
+            step(*stacks, gt, mask, it)
+        sync()
+        dt1 = time.time() - t1
+        p1, engine.PROFILE = engine.PROFILE, None
+        engine.CONV_MODE = mode
+        s1 = sum(e0.elapsed_time(e1) for _, _, e0, e1 in p1) * 1e-3
+        a1 = sum(f for _, f, _, _ in p1) / s1 / 1e12 if s1 > 0 else 0.0
+        f32_leg = {'value': round(args.global_batch * 2 / dt1, 3), 'unit': 'patches/s', 'steps': 2,
+                   'kernel': 'conv4tap_kernel<9> (v_mfma_f32_32x32x2_f32)', 'achieved': round(a1, 2),
+                   'peak': PEAK_F32_MFMA_TFLOPS, 'frac': round(a1 / PEAK_F32_MFMA_TFLOPS, 4)}
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -172,6 +193,8 @@ def main():
                          'algorithmic_bytes': round(2.0 * B * 98 * 98 * 280 * 4) if args.patch == 96 else None,
                          'launches': len(prof), 'avg_ms': round(1e3 * secs / max(1, len(prof)), 3)},
         }
+        if f32_leg is not None:
+            line['exact_f32_mfma_path'] = f32_leg
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.patch)
         print(json.dumps(line), flush=True)
