@@ -263,6 +263,11 @@ def test_error_convention():
     with pytest.raises(RuntimeError, match='mmlf_conv2x2'):
         call('mmlf_conv2x2', None, 32, 27, None, None, 70, None, 72, 72, 0, 1, 1, 1, 4, 4, 0, None, 0, None)
     x = torch.zeros(16, device=_dev())
+    for bad in ((0, 4, 4), (1, 0, 4), (1, 4, -1)):            # empty batch / empty image: rejected, not launched
+        with pytest.raises(RuntimeError, match='bad shape'):
+            call('mmlf_conv2x2', x.data_ptr(), 32, 27, x.data_ptr(), None, 70, x.data_ptr(), 72, 72, 0, 1, 1, *bad, 0,
+                 None, 0, None)
+    assert _lib.load().mmlf_grid_alloc_positions(0, 4, 4) == -1
     with pytest.raises(RuntimeError, match='cs_in'):
         call('mmlf_conv2x2', x.data_ptr(), 30, 27, x.data_ptr(), None, 70, x.data_ptr(), 72, 72, 0, 1, 1, 1, 4, 4, 0,
              None, 0, None)

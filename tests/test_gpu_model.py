@@ -201,3 +201,41 @@ def test_reference_train_loop_shape_dataparallel_adam_autograd():
             np.testing.assert_allclose(a.cpu().numpy()[solid.numpy()], g[f'post/{k}'][solid.numpy()], rtol=0, atol=3e-6, err_msg=k)
         else:
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_full_frame_512_equals_halo_tiles():
+    """BASELINE.json configs[4] size: a 512x512 frame through the un-tiled eval forward equals 11-px-halo
+    tiles of it (size-independent property; the two runs use different grid pitches / window modes)."""
+    kw = dict(BASE_KW, model_uncert=True)
+    m = _model(kw, synth.synth_state(synth.param_spec(**kw), seed=13))
+    m.eval()
+    stacks, _, _ = synth.synth_inputs(1, 512, seed=14)
+    ts = [torch.from_numpy(s).to(_dev()) for s in stacks]
+    with torch.no_grad():
+        full = m(*ts)
+        y0, x0, sz = 120, 300, 150                       # interior tile, odd size
+        tile = m(*[t[..., y0 - 11:y0 + sz + 11, x0 - 11:x0 + sz + 11].contiguous() for t in ts])
+    for k in ('mean', 'logvar'):
+        a = tile[k][:, 11:-11, 11:-11].cpu().numpy()
+        b = full[k][:, y0:y0 + sz, x0:x0 + sz].cpu().numpy()
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6, err_msg=k)
+    assert np.isfinite(full['posterior'].cpu().numpy()).all()
+
+
+def test_train_step_is_permutation_invariant_over_the_batch():
+    """BN statistics, the masked-mean loss and every gradient are sums over the batch: shuffling the
+    patches of a 96-patch ps=96 batch must not change the loss or the gradients (beyond summation order)."""
+    from mmlf_amd.train import TrainStep
+    dev = _dev()
+    state = synth.synth_state(synth.param_spec(**BASE_KW), seed=17)
+    stacks, gt, mask = synth.synth_inputs(96, 96, seed=18)
+    perm = np.random.RandomState(0).permutation(96)
+    res = []
+    for order in (np.arange(96), perm):
+        st = TrainStep(_model(BASE_KW, state), lr=1e-3)
+        data = [torch.from_numpy(s[order]).to(dev) for s in stacks]
+        loss = st(*data, torch.from_numpy(gt[order]).to(dev), torch.from_numpy(mask[order]).to(dev), 1)
+        res.append((float(loss), st.grad.clone()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
+    g0, g1 = res[0][1], res[1][1]
+    assert float((g0 - g1).norm()) <= 2e-2 * float(g0.norm())     # ReLU/sign flips: see DESIGN.md section 2
