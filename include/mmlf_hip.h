@@ -103,6 +103,11 @@ int mmlf_bn_stats_train(const float *z, int cs, int C, const float *gamma, const
 int mmlf_bn_coeffs_eval(const float *gamma, const float *beta, const float *running_mean,
                         const float *running_var, double eps, float *scale, float *shift, int C,
                         void *stream);
+/* eval-mode BatchNorm folded into the convolution in front of it (inference only):
+ * w_out[co,...] = w[co,...]*scale[co], bias_out = bias*scale + shift, so that conv + fused ReLU
+ * replaces conv, nn.BatchNorm2d(eval), nn.ReLU (feed_forward.py:125,134-135). */
+int mmlf_fold_bn_eval(const float *w_oihw, const float *bias, const float *scale, const float *shift,
+                      float *w_out, float *bias_out, int Cout, int Cin, void *stream);
 /* y[q][c_off + c] = interior(q) ? relu(z[q][c]*scale[c] + shift[c]) : 0   (BN apply + nn.ReLU,
  * feed_forward.py:134-135; writing a channel slice implements torch.cat, feed_forward.py:266-267) */
 int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *scale, const float *shift,

@@ -184,6 +184,21 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double *__res
     coef[2 * C + c] = (float)(k1 * (double)invstd[c] * sgx / n);
 }
 
+// eval-mode BatchNorm folded into the preceding convolution: w'[co] = w[co]*scale[co],
+// b' = b*scale + shift  (then conv + ReLU is the whole block tail; no BN pass over the activations)
+__global__ void fold_bn_kernel(const float *__restrict__ w, const float *__restrict__ b,
+                               const float *__restrict__ scale, const float *__restrict__ shift,
+                               float *__restrict__ w_out, float *__restrict__ b_out, int Cout, int per_co)
+{
+    const long long total = (long long)Cout * per_co;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i / per_co);
+        w_out[i] = w[i] * scale[co];
+        if (i % per_co == 0) b_out[co] = fmaf(b ? b[co] : 0.f, scale[co], shift[co]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // row-wise elementwise kernels: one block per grid row (b, y), y in [0, R)
 // MODE 0: y = relu(z*scale+shift) (interior) | MODE 1: dz = k1*g - k2 - k3*(z-mean), g = gy*(u>0)
@@ -590,6 +605,16 @@ extern "C" int mmlf_bn_coeffs_eval(const float *gamma, const float *beta, const 
     hipLaunchKernelGGL(bn_coeffs_eval_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gamma, beta, rm,
                        rv, eps, scale, shift, C);
     return mmlf_launch_status("mmlf_bn_coeffs_eval");
+}
+
+extern "C" int mmlf_fold_bn_eval(const float *w_oihw, const float *bias, const float *scale, const float *shift,
+                                 float *w_out, float *bias_out, int Cout, int Cin, void *stream)
+{
+    MMLF_CHECK_ARG(w_oihw && scale && shift && w_out && bias_out && Cout > 0 && Cin > 0, "mmlf_fold_bn_eval: bad argument");
+    const long long total = (long long)Cout * Cin * 4;
+    hipLaunchKernelGGL(fold_bn_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, w_oihw, bias, scale,
+                       shift, w_out, bias_out, Cout, Cin * 4);
+    return mmlf_launch_status("mmlf_fold_bn_eval");
 }
 
 extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *scale, const float *shift, float *y,

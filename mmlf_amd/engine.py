@@ -93,12 +93,14 @@ def pack_filter(w, variant, dgrad):
 PROFILE = None   # bench.py sets this to a list to time the dominant conv launches with HIP events
 
 
-def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0):
+def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0,
+         n_store=None, out_off=0):
     prof = PROFILE is not None and K >= 256 and N >= 256
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call('mmlf_conv2x2_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2', ptr(x), cs_in, K, ptr(packed), ptr(bias), N, ptr(out), cs_out, cs_out, out_shift,
+    call('mmlf_conv2x2_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2', ptr(x), cs_in, K, ptr(packed), ptr(bias), N,
+         ptr(out) + 4 * out_off, cs_out, cs_out if n_store is None else n_store, out_shift,
          vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref, _lib.stream_ptr())
     if prof:
         e1.record()
@@ -141,14 +143,34 @@ class Trunk:
         w1, b1 = p[f'{spec.prefix}.0.weight'], p[f'{spec.prefix}.0.bias']
         w2, b2 = p[f'{spec.prefix}.2.weight'], p[f'{spec.prefix}.2.bias']
         pk1 = pack_filter(w1, var, False)
-        pk2 = pack_filter(w2, var, False)
         y = geo.buf(cs_mid, dev)
         conv(geo, x, cs_x, spec.cin, pk1, b1, cmid, y, cs_mid, 0, H + 1, W + 1, True)
+        if spec.bn and not train and rec_list is None:   # rec_list is None when nothing is saved for backward
+            # inference: BatchNorm(eval) is a per-channel affine map -> fold it into conv2 and fuse the ReLU
+            C = spec.cout
+            coef = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            call('mmlf_bn_coeffs_eval', ptr(p[f'{spec.prefix}.3.weight']), ptr(p[f'{spec.prefix}.3.bias']),
+                 ptr(p[f'{spec.prefix}.3.running_mean']), ptr(p[f'{spec.prefix}.3.running_var']), self.eps,
+                 ptr(coef), ptr(coef[C:]), C, _lib.stream_ptr())
+            w2f, b2f = torch.empty_like(w2), torch.empty_like(b2)
+            call('mmlf_fold_bn_eval', ptr(w2), ptr(b2), ptr(coef), ptr(coef[C:]), ptr(w2f), ptr(b2f), C, C,
+                 _lib.stream_ptr())
+            pk2 = pack_filter(w2f, var, False)
+            if out is None:
+                cs_out, c_off = cs_mid, 0
+                out = geo.buf(cs_out, dev)
+                n_store = cs_out
+            else:
+                n_store = C
+            conv(geo, y, cs_mid, cmid, pk2, b2f, cmid, out, cs_out, P + 1, H, W, True, n_store=n_store, out_off=c_off)
+            return out, cs_out
+        pk2 = pack_filter(w2, var, False)
         z = geo.buf(cs_mid, dev)
         conv(geo, y, cs_mid, cmid, pk2, b2, cmid, z, cs_mid, P + 1, H, W, False)
         rec = {'spec': spec, 'var': var, 'x': x, 'cs_x': cs_x, 'y': y, 'z': z}
         if not spec.bn:
-            rec_list.append(rec)
+            if rec_list is not None:
+                rec_list.append(rec)
             return z, cs_mid
         C = spec.cout
         coef = torch.empty(4 * C, dtype=torch.float32, device=dev)
@@ -172,7 +194,8 @@ class Trunk:
         call('mmlf_bn_apply_relu', ptr(z), cs_mid, C, ptr(scale), ptr(shift), ptr(out), cs_out, c_off, c_store,
              B, H, W, _lib.stream_ptr())
         rec.update(scale=scale, shift=shift, smean=smean, sinv=sinv)
-        rec_list.append(rec)
+        if rec_list is not None:
+            rec_list.append(rec)
         return out, cs_out
 
     def forward(self, p, stacks, train, save):
@@ -192,14 +215,14 @@ class Trunk:
             recs = []
             for k, spec in enumerate(blocks):
                 last = k == len(blocks) - 1
-                x, cs_x = self._block_fwd(geo, spec, var, x, cs_x, p, train, recs,
+                x, cs_x = self._block_fwd(geo, spec, var, x, cs_x, p, train, recs if save else None,
                                           out=concat if last else None, cs_out=4 * self.chs, c_off=s * self.chs)
             tape['streams'].append(recs)
             if not save:
                 del recs[:]
         x, cs_x = concat, 4 * self.chs
         for spec in self.out_blocks:
-            x, cs_x = self._block_fwd(geo, spec, VAR_IDENTITY, x, cs_x, p, train, tape['out'])
+            x, cs_x = self._block_fwd(geo, spec, VAR_IDENTITY, x, cs_x, p, train, tape['out'] if save else None)
             if not save:
                 del tape['out'][:]
         out = torch.empty((B, self.oc, H, W), dtype=torch.float32, device=dev)
