@@ -296,10 +296,10 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(Con
             if (more) {
                 if (w < 4) {
                     if (g == 0) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
-                    if (g == NT) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
+                    if (g == G / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
                 } else {
-                    if (g == NT / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
-                    if (g == NT + NT / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
+                    if (g == G / 4) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
+                    if (g == G / 2 + G / 4) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -371,12 +371,14 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
 
 // 16x16x32-MFMA variant of conv4tap_x6_kernel (K = 32 = the whole 4-tap x 8-channel chunk per MFMA;
 // lane quarter q = lane>>4 carries tap q).  Weight layout [chunk][plane(3)][q(4)][NP][8 bf16].
-// NT <= 3: cap VGPRs at 128 so that TWO workgroups share a CU (LDS 2 x 39 KB x 2): with only
+// VGPRs capped at 128 so that TWO workgroups share a CU (LDS 2 x 39 KB x 2): with only
 // 36 MFMAs per wave per chunk the DMA latency of a single double-buffered workgroup is exposed.
-template <int NT>
-__global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
+// G = number of 16-column output blocks (NP = 16*G packed columns): 2, 5 (the 70-channel layers: 80
+// columns instead of 96) or 6.
+template <int G>
+__global__ __launch_bounds__(512, 4) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
 {
-    constexpr int NP = NT * 32;
+    constexpr int NP = G * 16;
     // A: [channel half(2)][640 slots] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
     // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
     // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
@@ -388,7 +390,6 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6s_kernel(Co
     constexpr int N_B = B_F4 / 64;
     constexpr int PER_WAVE = (20 + N_B + 7) / 8;      // upper bound (two-segment mode: 20 A pieces)
     constexpr int PER_SLOT = (PER_WAVE + 1) / 2;
-    constexpr int G = 2 * NT;                   // MFMA groups: one 16-column block x 2 row blocks x 6 passes
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *lds = reinterpret_cast<float4 *>(smem);
 
@@ -504,10 +505,10 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6s_kernel(Co
             if (more) {
                 if (w < 4) {
                     if (g == 0) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
-                    if (g == NT) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
+                    if (g == G / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
                 } else {
-                    if (g == NT / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
-                    if (g == NT + NT / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
+                    if (g == G / 4) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
+                    if (g == G / 2 + G / 4) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1143,13 +1144,23 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
 // ------------------------------------------------------------------ split-bf16 ("bf16x6") entry points
 // narrow layers (N <= 96) run the 16x16x32-MFMA variant (measured ~10 % faster there; the 32x32x16
 // variant wins at N = 288).  Packing and launch pick by the same rule, so the layouts always agree.
-static inline int x6_shape16(int nt) { return nt <= 3; }
+// Packed column count NP of the split forward/dgrad kernels: 16-column granularity up to 96, then the
+// 32x32 tilings.  Packing and launch pick by this one rule, so the layouts always agree.
+static inline int x6_np(int N)
+{
+    if (N <= 0 || N > 288) return -1;
+    if (N <= 32) return 32;
+    if (N <= 80) return 80;
+    if (N <= 96) return 96;
+    return N <= 128 ? 128 : 288;
+}
+static inline int x6_shape16(int np) { return np <= 96; }
 
 extern "C" int64_t mmlf_packed_filter_split_bytes(int K, int N)
 {
-    const int nt = pick_nt(N);
-    if (nt < 0 || K <= 0) return -1;
-    return (int64_t)((K + 7) / 8) * 12 * (nt * 32) * 16;
+    const int np = x6_np(N);
+    if (np < 0 || K <= 0) return -1;
+    return (int64_t)((K + 7) / 8) * 12 * np * 16;
 }
 
 extern "C" int mmlf_pack_filter_split(const float *w, void *packed, int Cout, int Cin, int variant, int dgrad,
@@ -1158,17 +1169,31 @@ extern "C" int mmlf_pack_filter_split(const float *w, void *packed, int Cout, in
     MMLF_CHECK_ARG(w && packed, "mmlf_pack_filter_split: null pointer");
     MMLF_CHECK_ARG(variant >= 0 && variant <= 2, "mmlf_pack_filter_split: bad variant %d", variant);
     const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-    const int nt = pick_nt(N);
-    MMLF_CHECK_ARG(nt > 0, "mmlf_pack_filter_split: N=%d not supported (max 288)", N);
-    const int nchunk = (K + 7) / 8, NP = nt * 32;
+    const int NP = x6_np(N);
+    MMLF_CHECK_ARG(NP > 0, "mmlf_pack_filter_split: N=%d not supported (max 288)", N);
+    const int nchunk = (K + 7) / 8;
     const long long total = (long long)nchunk * 32 * NP;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_filter_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                       (unsigned short *)packed, Cout, Cin, variant, dgrad, nchunk, NP, x6_shape16(nt));
+                       (unsigned short *)packed, Cout, Cin, variant, dgrad, nchunk, NP, x6_shape16(NP));
     return mmlf_launch_status("mmlf_pack_filter_split");
 }
 
+static int device_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// persistent launches: one workgroup per CU (two for the narrow variant), each walks tiles b, b+grid, ...
 template <int NT>
 static int launch_conv_x6(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
@@ -1179,28 +1204,25 @@ static int launch_conv_x6(const ConvArgs &a, long long ntiles, hipStream_t st)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    // persistent: one workgroup per CU (two for the narrow variants), each walks tiles b, b+grid, ...
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    long long grid = (long long)cus * (NT <= 3 ? 2 : 1);
+    long long grid = device_cus();
     if (grid > ntiles) grid = ntiles;
-    if (x6_shape16(NT)) {
-        static bool attr16 = false;
-        if (!attr16) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<NT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr16 = true;
-        }
-        hipLaunchKernelGGL(conv4tap_x6s_kernel<NT>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
-    } else {
-        hipLaunchKernelGGL(conv4tap_x6_kernel<NT>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
+    hipLaunchKernelGGL(conv4tap_x6_kernel<NT>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
+    return mmlf_launch_status("mmlf_conv2x2_split");
+}
+
+template <int G>
+static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
+{
+    constexpr size_t lds = 2 * (2 * 640 + 12 * G * 16) * sizeof(float4);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
     }
+    long long grid = 2ll * device_cus();
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(conv4tap_x6s_kernel<G>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
     return mmlf_launch_status("mmlf_conv2x2_split");
 }
 
@@ -1212,10 +1234,10 @@ extern "C" int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void 
     MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0, "mmlf_conv2x2_split: bad shape B=%d H=%d W=%d", B, H, W);
     MMLF_CHECK_ARG(cs_in > 0 && cs_in % 8 == 0, "mmlf_conv2x2_split: cs_in=%d must be a multiple of 8", cs_in);
     MMLF_CHECK_ARG(K > 0 && (K + 7) / 8 * 8 == cs_in, "mmlf_conv2x2_split: K=%d does not match cs_in=%d", K, cs_in);
-    const int nt = pick_nt(N);
-    MMLF_CHECK_ARG(nt > 0, "mmlf_conv2x2_split: N=%d not supported (max 288)", N);
-    MMLF_CHECK_ARG(N_store > 0 && N_store <= cs_out && N_store <= nt * 32,
-                   "mmlf_conv2x2_split: N_store=%d vs cs_out=%d NP=%d", N_store, cs_out, nt * 32);
+    const int np = x6_np(N);
+    MMLF_CHECK_ARG(np > 0, "mmlf_conv2x2_split: N=%d not supported (max 288)", N);
+    MMLF_CHECK_ARG(N_store > 0 && N_store <= cs_out && N_store <= np,
+                   "mmlf_conv2x2_split: N_store=%d vs cs_out=%d NP=%d", N_store, cs_out, np);
     Grid g = make_grid(B, H, W);
     MMLF_CHECK_ARG(out_shift >= 0 && out_shift <= g.P + 1, "mmlf_conv2x2_split: out_shift=%d", out_shift);
     MMLF_CHECK_ARG(!relu_ref || cs_ref >= N_store, "mmlf_conv2x2_split: cs_ref=%d < N_store", cs_ref);
@@ -1231,10 +1253,11 @@ extern "C" int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void 
     }
     const long long ntiles = g.NQpad / MMLF_TILE;
     hipStream_t st = (hipStream_t)stream;
-    switch (nt) {
-    case 1: return launch_conv_x6<1>(a, ntiles, st);
-    case 3: return launch_conv_x6<3>(a, ntiles, st);
-    case 4: return launch_conv_x6<4>(a, ntiles, st);
+    switch (np) {
+    case 32: return launch_conv_x6s<2>(a, ntiles, st);
+    case 80: return launch_conv_x6s<5>(a, ntiles, st);
+    case 96: return launch_conv_x6s<6>(a, ntiles, st);
+    case 128: return launch_conv_x6<4>(a, ntiles, st);
     default: return launch_conv_x6<9>(a, ntiles, st);
     }
 }
