@@ -960,6 +960,138 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6_kernel(WgradArgs a)
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// narrow-layer weight gradient (Cin + 1 <= 16*MB rows, Cout <= 16*NB columns; the 70-channel stream
+// layers: 80 x 80 instead of three 32-row slices x 96 columns = 1.85x the useful MFMA work).
+// One workgroup holds ALL input channels, so the gradient tile is staged and split once; wave t = tap t
+// accumulates MB x NB tiles of v_mfma_f32_16x16x32_bf16 (K = the chunk's 32 positions).
+// LDS rows are 160 B (40 dwords): the 8 position rows one half-wave touches in a transposed read then
+// start on 8 distinct multiples of 8 banks.  Lane group q4 takes positions {4q4..4q4+3, 16+4q4..}: the
+// k order is the same permutation for both operands, which a dot product does not see.
+// ---------------------------------------------------------------------------------------------
+template <int MB, int NB>
+__global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
+{
+    static_assert(MB <= 5 && NB <= 5, "LDS row holds 80 channels");
+    constexpr int ROWB = 160;
+    constexpr int A_PLANE = 34 * ROWB;            // per (seg, plane)
+    constexpr int A_BYTES = 6 * A_PLANE;
+    constexpr int G_PLANE = WG_KQ * ROWB;
+    constexpr int FA = 4 * MB, FG = 4 * NB;       // float4 per staged row
+    constexpr int NA = (66 * FA + 255) / 256, NG = (WG_KQ * FG + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *As = smem;
+    char *Gs = smem + A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, t = tid >> 6;
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int split = blockIdx.x;
+    int c_begin = split * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > a.nchunks) c_end = a.nchunks;
+
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
+
+    float4 ra[NA], rg[NG];
+#define WN_GLOAD(c)                                                                                         \
+    do {                                                                                                    \
+        const long long Qc = (long long)(c) * WG_KQ;                                                        \
+        _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
+            const int idx = tid + 256 * j;                                                                  \
+            const int row = idx / FA, f = idx - row * FA;                                                   \
+            const int seg = row >= 33, pix = row - 33 * seg;                                                \
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+            if (idx < 66 * FA && 4 * f < a.cs_in)                                                           \
+                v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + 4 * f); \
+            ra[j] = v;                                                                                      \
+        }                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
+            const int idx = tid + 256 * j;                                                                  \
+            const int row = idx / FG, f = idx - row * FG;                                                   \
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+            if (idx < WG_KQ * FG && 4 * f < a.cs_g)                                                         \
+                v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + 4 * f); \
+            rg[j] = v;                                                                                      \
+        }                                                                                                   \
+    } while (0)
+#define WN_LSTORE()                                                                                         \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
+            const int idx = tid + 256 * j;                                                                  \
+            if (idx < 66 * FA) {                                                                            \
+                const int row = idx / FA, f = idx - row * FA;                                               \
+                const int seg = row >= 33, pix = row - 33 * seg;                                            \
+                float4 v = ra[j];                                                                           \
+                const int ch = 4 * f;     /* ones row -> bias gradient */                                   \
+                if (ch == a.cin) v.x = 1.f;                                                                 \
+                if (ch + 1 == a.cin) v.y = 1.f;                                                             \
+                if (ch + 2 == a.cin) v.z = 1.f;                                                             \
+                if (ch + 3 == a.cin) v.w = 1.f;                                                             \
+                split_store4(v, As + seg * 3 * A_PLANE + pix * ROWB + 8 * f, A_PLANE);                      \
+            }                                                                                               \
+        }                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
+            const int idx = tid + 256 * j;                                                                  \
+            if (idx < WG_KQ * FG) {                                                                         \
+                const int row = idx / FG, f = idx - row * FG;                                               \
+                split_store4(rg[j], Gs + row * ROWB + 8 * f, G_PLANE);                                      \
+            }                                                                                               \
+        }                                                                                                   \
+    } while (0)
+
+    // transposed-read geometry: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const char *a_lane = As + (t >> 1) * 3 * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWB + 8 * tp;
+    const char *g_lane = Gs + (4 * q4 + tq) * ROWB + 8 * tp;
+
+    if (c_begin < c_end) {
+        WN_GLOAD(c_begin);
+        for (int c = c_begin; c < c_end; ++c) {
+            WN_LSTORE();
+            __syncthreads();
+            if (c + 1 < c_end) WN_GLOAD(c + 1);
+            bf16x8 gf[NB][3];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) gf[nb][pl] = tr_frag(g_lane + pl * G_PLANE + 32 * nb, 4 * ROWB);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[pl] = tr_frag(a_lane + pl * A_PLANE + 32 * mb, 4 * ROWB);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], gf[nb][0], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[nb][2], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[nb][1], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[nb][0], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[nb][1], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[nb][0], acc[mb][nb], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+#undef WN_GLOAD
+#undef WN_LSTORE
+    constexpr int CIP = 16 * MB, NP = 16 * NB;
+    float *pp = a.part + (size_t)(split * 4 + t) * CIP * NP;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pp[(size_t)(16 * mb + 4 * q4 + r) * NP + 16 * nb + r16] = acc[mb][nb][r];
+}
+
 // sum the position splits and scatter to the OIHW master gradient (+ bias gradient)
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, float *__restrict__ gb,
                                     int Cin, int Cout, int CIP, int NP, int nsplit, int variant, int accumulate)
@@ -1000,12 +1132,23 @@ extern "C" int64_t mmlf_packed_filter_floats(int K, int N)
     return (int64_t)((K + 7) / 8) * 4 * 2 * (nt * 32) * 4;
 }
 
+// split-arithmetic narrow kernel: 16-row blocks MB (Cin + ones row) when the layer fits 80 x 80, else 0
+static inline int wgrad_narrow_mb(int Cin, int Cout)
+{
+    if (Cout <= 32 || Cout > 80 || Cin + 1 > 80) return 0;
+    return Cin + 1 <= 32 ? 2 : 5;
+}
+#define WGRAD_NARROW_NSPLIT 512   // two 256-thread blocks per CU on 256 CUs
+
 extern "C" int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout)
 {
     const int nt = pick_nt(Cout);
     if (nt < 0) return -1;
     const int nslice = (Cin + 1 + 31) / 32;
-    return (int64_t)wgrad_nsplit(nslice) * 4 * (nslice * 32) * (nt * 32);
+    int64_t n = (int64_t)wgrad_nsplit(nslice) * 4 * (nslice * 32) * (nt * 32);
+    const int mb = wgrad_narrow_mb(Cin, Cout);
+    if (mb && n < (int64_t)WGRAD_NARROW_NSPLIT * 4 * (16 * mb) * 80) n = (int64_t)WGRAD_NARROW_NSPLIT * 4 * (16 * mb) * 80;
+    return n;
 }
 
 extern "C" int mmlf_pack_filter(const float *w, float *packed, int Cout, int Cin, int variant, int dgrad,
@@ -1087,6 +1230,14 @@ static int launch_wgrad(const WgradArgs &a, hipStream_t st, int split_bf16)
     return mmlf_launch_status("mmlf_conv2x2_wgrad");
 }
 
+template <int MB, int NB>
+static int launch_wgrad_narrow(const WgradArgs &a, hipStream_t st)
+{
+    constexpr size_t lds = 6 * 34 * 160 + 3 * WG_KQ * 160;
+    hipLaunchKernelGGL((wgrad4tap_x6n_kernel<MB, NB>), dim3((unsigned)a.nsplit), dim3(256), lds, st, a);
+    return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
+}
+
 static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout, int g_shift,
                       float *gw, float *gb, int variant, int accumulate, float *workspace, int B, int H, int W,
                       void *stream, int split_bf16);
@@ -1128,6 +1279,18 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
     a.chunks_per_split = (a.nchunks + a.nsplit - 1) / a.nsplit;
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    const int mb = split_bf16 ? wgrad_narrow_mb(Cin, Cout) : 0;
+    if (mb) {
+        a.nslice = 1;
+        a.nsplit = WGRAD_NARROW_NSPLIT;
+        a.chunks_per_split = (a.nchunks + a.nsplit - 1) / a.nsplit;
+        rc = mb == 2 ? launch_wgrad_narrow<2, 5>(a, st) : launch_wgrad_narrow<5, 5>(a, st);
+        if (rc) return rc;
+        const int total = 4 * (Cin + 1) * Cout;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw, gb, Cin,
+                           Cout, 16 * mb, 80, a.nsplit, variant, accumulate);
+        return mmlf_launch_status("mmlf_conv2x2_wgrad(reduce)");
+    }
     switch (nt) {
     case 1: rc = launch_wgrad<1>(a, st, split_bf16); break;
     case 3: rc = launch_wgrad<3>(a, st, split_bf16); break;

@@ -124,7 +124,7 @@ def test_filter_variants_equal_image_transforms(oracle, variant):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize('cin,cout', [(27, 70), (70, 70), (280, 280), (280, 2), (2, 2), (280, 108), (32, 8)])
+@pytest.mark.parametrize('cin,cout', [(27, 70), (70, 70), (280, 280), (280, 2), (2, 2), (280, 108), (32, 8), (79, 80), (31, 33)])
 @pytest.mark.parametrize('pad', [1, 0])
 @pytest.mark.parametrize('variant', [0, 2])
 @pytest.mark.parametrize('mode', ['f32', 'bf16x6'])
