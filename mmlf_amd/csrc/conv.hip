@@ -54,31 +54,66 @@ struct ConvArgs {
 
 // epilogue shared by the f32 and the split-bf16 kernels: D[row = position][col = channel]; a lane
 // holds column i of every N tile and rows (r&3)+8(r>>2)+4kh of its wave's 32 positions.
+// Epilogues.  All eight waves of a workgroup run theirs at the same time, so the matrix cores idle
+// meanwhile: written for few instructions and few serialized memory round trips.
+//  * row validity: lane l classifies row l&31 of the wave's 32 positions (ONE division per lane) and a
+//    ballot makes the 32-bit row mask;
+//  * addressing: buffer instructions on a wave-uniform tile descriptor + 32-bit per-lane byte offsets
+//    (the column-block offset folds into the instruction's immediate);
+//  * bias and (data-gradient) ReLU-reference values are loaded in batches ahead of their use.
+#define MMLF_BUF_FLAGS 0x00020000   // raw dword buffer (DATA_FORMAT_32), no swizzle
+__device__ __forceinline__ unsigned wave_row_mask(const ConvArgs &a, long long Q0, int w, int lane)
+{
+    const int qrow = (int)Q0 + 32 * w + (lane & 31);
+    const int rem = qrow % a.G;
+    const int y = rem / a.P, x = rem - y * a.P;
+    return (unsigned)__ballot(qrow < a.NQ && y < a.vh && x < a.vw);
+}
+
+// 32x32 tiling: lane (i, kh) holds column i of each 32-column block, rows (r&3) + 8*(r>>2) + 4*kh.
 template <int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&acc)[NT], long long Q0, int w, int i,
                                               int kh)
 {
-    unsigned valid = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = (int)Q0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int rem = q % a.G;
-        const int y = rem / a.P, x = rem - y * a.P;
-        if (q < a.NQ && y < a.vh && x < a.vw) valid |= 1u << r;
-    }
+    const unsigned m = wave_row_mask(a, Q0, w, i) >> (4 * kh);
+    const long long qb = Q0 + 32 * w + a.out_shift;                                     // wave-uniform
+    const __amdgpu_buffer_rsrc_t ob =
+        __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)qb * a.cs_out, 0, 0x7fffffff, MMLF_BUF_FLAGS);
+    const bool has_ref = a.ref != nullptr;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(has_ref ? a.ref + (size_t)qb * a.cs_ref : a.out), 0, 0x7fffffff, MMLF_BUF_FLAGS);
+    unsigned lo = ((unsigned)(4 * kh) * a.cs_out + i) * 4u;
+    unsigned lr = ((unsigned)(4 * kh) * a.cs_ref + i) * 4u;
+    // the per-row offsets derived from these are tile-invariant: opaque to the optimiser so that it does
+    // not hoist 32 of them out of the persistent loop and hold them in VGPRs through the main loop
+    asm volatile("" : "+v"(lo), "+v"(lr));
+    float bv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int ch = 32 * nt + i;
-        if (ch >= a.n_store) continue;
-        const float bv = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
+        bv[nt] = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (32 * nt + i >= a.n_store) continue;
+        unsigned keep = m;                 // bit rc: row valid (and, for a data gradient, reference > 0)
+        if (has_ref) {
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    rb, lr + (unsigned)((r & 3) + 8 * (r >> 2)) * a.cs_ref * 4u + 128 * nt, 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (!(rv[r] > 0.f)) keep &= ~(1u << ((r & 3) + 8 * (r >> 2)));
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long long q = Q0 + 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh + a.out_shift;
-            float v = acc[nt][r] + bv;
+            const int rc = (r & 3) + 8 * (r >> 2);
+            float v = acc[nt][r] + bv[nt];
             if (a.relu) v = fmaxf(v, 0.f);
-            if (a.ref) v = (a.ref[(size_t)q * a.cs_ref + ch] > 0.f) ? v : 0.f;
-            v = (valid >> r & 1) ? v : 0.f;
-            a.out[(size_t)q * a.cs_out + ch] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((keep >> rc & 1) ? v : 0.f), ob,
+                                                  lo + (unsigned)rc * a.cs_out * 4u + 128 * nt, 0, 0);
         }
     }
 }
@@ -202,10 +237,13 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(Con
     const char *wp_base = reinterpret_cast<const char *>(a.wp);
     const size_t tile_bytes = (size_t)MMLF_TILE * a.cs_in * 4;
     const int n_a = 2 * a.a_pieces, n_pieces = n_a + N_B;
+    // the wave index as the DMA macros see it: re-made opaque every chunk, so that the per-piece address
+    // terms derived from it are recomputed on the scalar unit instead of hoisted into (spilled) SGPRs
+    int wj = w;
 
 #define X6_DMA_PIECE(tl, c, buf, k)                                                                      \
     do {                                                                                                 \
-        const int j_ = w + 8 * (k);                                                                      \
+        const int j_ = wj + 8 * (k);                                                                     \
         if ((k) < PER_WAVE && j_ < n_pieces) {                                                           \
             const char *sb_;                                                                             \
             unsigned vo_, d_;                                                                            \
@@ -253,6 +291,7 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(Con
     int buf = 0;
 
     while (tile < ntiles) {
+        asm volatile("" : "+s"(wj));
         const bool more = ntile < ntiles;
         const float4 *base = lds + buf * BUF_F4;
         const float4 *ap = base + 32 * w + i + kh;             // + u * seg_slot + half * A_HALF
@@ -334,38 +373,45 @@ __global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(Con
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// epilogue for 16x16 accumulator tiles: lane holds column r16 of each 16-column block and rows
-// 4*q4 + r (r = 0..3) of each 16-position row block.
+// 16x16 tiling: lane (r16, q4) holds column r16 of each 16-column block and rows 16*mb + 4*q4 + r.
 template <int G>
 __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (&acc)[2][G], long long Q0, int w,
                                                 int r16, int q4)
 {
-    unsigned valid = 0;
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = (int)Q0 + 32 * w + 16 * mb + 4 * q4 + r;
-            const int rem = q % a.G;
-            const int y = rem / a.P, x = rem - y * a.P;
-            if (q < a.NQ && y < a.vh && x < a.vw) valid |= 1u << (4 * mb + r);
-        }
+    const unsigned m = wave_row_mask(a, Q0, w, r16 + 16 * q4) >> (4 * q4);
+    const long long qb = Q0 + 32 * w + a.out_shift;                                     // wave-uniform
+    const __amdgpu_buffer_rsrc_t ob =
+        __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)qb * a.cs_out, 0, 0x7fffffff, MMLF_BUF_FLAGS);
+    const bool has_ref = a.ref != nullptr;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(has_ref ? a.ref + (size_t)qb * a.cs_ref : a.out), 0, 0x7fffffff, MMLF_BUF_FLAGS);
+    unsigned lo = ((unsigned)(4 * q4) * a.cs_out + r16) * 4u;
+    unsigned lr = ((unsigned)(4 * q4) * a.cs_ref + r16) * 4u;
+    asm volatile("" : "+v"(lo), "+v"(lr));   // see conv_epilogue
 #pragma unroll
     for (int nb = 0; nb < G; ++nb) {
         const int ch = 16 * nb + r16;
         if (ch >= a.n_store) continue;
-        const float bv = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
+        const float bvn = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
+        unsigned keep = m;
+        if (has_ref) {
+            float rv[8];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+            for (int k = 0; k < 8; ++k)
+                rv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                    rb, lr + (unsigned)(16 * (k >> 2) + (k & 3)) * a.cs_ref * 4u + 64 * nb, 0, 0));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long q = Q0 + 32 * w + 16 * mb + 4 * q4 + r + a.out_shift;
-                float v = acc[mb][nb][r] + bv;
-                if (a.relu) v = fmaxf(v, 0.f);
-                if (a.ref) v = (a.ref[(size_t)q * a.cs_ref + ch] > 0.f) ? v : 0.f;
-                v = (valid >> (4 * mb + r) & 1) ? v : 0.f;
-                a.out[(size_t)q * a.cs_out + ch] = v;
-            }
+            for (int k = 0; k < 8; ++k)
+                if (!(rv[k] > 0.f)) keep &= ~(1u << (16 * (k >> 2) + (k & 3)));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int rc = 16 * (k >> 2) + (k & 3);
+            float v = acc[k >> 2][nb][k & 3] + bvn;
+            if (a.relu) v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((keep >> rc & 1) ? v : 0.f), ob,
+                                                  lo + (unsigned)rc * a.cs_out * 4u + 64 * nb, 0, 0);
+        }
     }
 }
 
@@ -376,7 +422,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
 // G = number of 16-column output blocks (NP = 16*G packed columns): 2, 5 (the 70-channel layers: 80
 // columns instead of 96) or 6.
 template <int G>
-__global__ __launch_bounds__(512, 4) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
+__global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
 {
     constexpr int NP = G * 16;
     // A: [channel half(2)][640 slots] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
@@ -414,10 +460,13 @@ __global__ __launch_bounds__(512, 4) void conv4tap_x6s_kernel(ConvArgs a, int nt
     const char *wp_base = reinterpret_cast<const char *>(a.wp);
     const size_t tile_bytes = (size_t)MMLF_TILE * a.cs_in * 4;
     const int n_a = 2 * a.a_pieces, n_pieces = n_a + N_B;
+    // the wave index as the DMA macros see it: re-made opaque every chunk, so that the per-piece address
+    // terms derived from it are recomputed on the scalar unit instead of hoisted into (spilled) SGPRs
+    int wj = w;
 
 #define X6_DMA_PIECE(tl, c, buf, k)                                                                      \
     do {                                                                                                 \
-        const int j_ = w + 8 * (k);                                                                      \
+        const int j_ = wj + 8 * (k);                                                                     \
         if ((k) < PER_WAVE && j_ < n_pieces) {                                                           \
             const char *sb_;                                                                             \
             unsigned vo_, d_;                                                                            \
@@ -465,6 +514,7 @@ __global__ __launch_bounds__(512, 4) void conv4tap_x6s_kernel(ConvArgs a, int nt
     int buf = 0;
 
     while (tile < ntiles) {
+        asm volatile("" : "+s"(wj));
         const bool more = ntile < ntiles;
         const float4 *base = lds + buf * BUF_F4;
         // lane (r16, q4): row r16 of a 16-position block, tap q4 -> slot offset (q4&1) + (q4>>1)*seg_slot
@@ -1314,10 +1364,9 @@ static inline int x6_np(int N)
     if (N <= 0 || N > 288) return -1;
     if (N <= 32) return 32;
     if (N <= 80) return 80;
-    if (N <= 96) return 96;
-    return N <= 128 ? 128 : 288;
+    if (N <= 128) return (N + 15) / 16 * 16;
+    return 288;
 }
-static inline int x6_shape16(int np) { return np <= 96; }
 
 extern "C" int64_t mmlf_packed_filter_split_bytes(int K, int N)
 {
@@ -1339,7 +1388,7 @@ extern "C" int mmlf_pack_filter_split(const float *w, void *packed, int Cout, in
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_filter_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                       (unsigned short *)packed, Cout, Cin, variant, dgrad, nchunk, NP, x6_shape16(NP));
+                       (unsigned short *)packed, Cout, Cin, variant, dgrad, nchunk, NP, 1);
     return mmlf_launch_status("mmlf_pack_filter_split");
 }
 
@@ -1383,7 +1432,7 @@ static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    long long grid = 2ll * device_cus();
+    long long grid = (G <= 6 ? 2ll : 1ll) * device_cus();
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(conv4tap_x6s_kernel<G>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
     return mmlf_launch_status("mmlf_conv2x2_split");
@@ -1420,7 +1469,8 @@ extern "C" int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void 
     case 32: return launch_conv_x6s<2>(a, ntiles, st);
     case 80: return launch_conv_x6s<5>(a, ntiles, st);
     case 96: return launch_conv_x6s<6>(a, ntiles, st);
-    case 128: return launch_conv_x6<4>(a, ntiles, st);
-    default: return launch_conv_x6<9>(a, ntiles, st);
+    case 112: return launch_conv_x6s<7>(a, ntiles, st);
+    case 128: return launch_conv_x6s<8>(a, ntiles, st);
+    default: return launch_conv_x6s<18>(a, ntiles, st);
     }
 }
