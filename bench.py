@@ -173,7 +173,7 @@ def main():
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         split = engine.CONV_MODE == 'bf16x6'
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
-        kname = 'conv4tap_x6_kernel<9>' if split else 'conv4tap_kernel<9>'
+        kname = 'conv4tap_x6s_kernel<18>' if split else 'conv4tap_kernel<9>'
         line = {
             'metric': '96x96 EPI patches/sec fwd+bwd, bs=512', 'value': round(value, 3), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),

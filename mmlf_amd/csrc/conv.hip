@@ -49,7 +49,7 @@ struct ConvArgs {
     const float *ref;
     long long NQ;
     int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
-    int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6_kernel)
+    int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6s_kernel)
 };
 
 // epilogue shared by the f32 and the split-bf16 kernels: D[row = position][col = channel]; a lane
@@ -154,9 +154,9 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsig
     l = cvt_pk_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xFFFF0000u));
 }
 
-// split-precision filter packing: [chunk][u(2)][plane(3)][kh(2)][NP][8 bf16], tap = 2u+kh, k = 8*chunk+j
+// split-precision filter packing: [chunk][plane(3)][tap(4)][NP][8 bf16], k = 8*chunk+j
 __global__ void pack_filter_split_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Cout,
-                                         int Cin, int variant, int dgrad, int nchunk, int NP, int layout16)
+                                         int Cin, int variant, int dgrad, int nchunk, int NP)
 {
     const long long total = (long long)nchunk * 2 * 2 * NP * 8;   // one thread per (chunk,u,kh,n,j)
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -176,9 +176,7 @@ __global__ void pack_filter_split_kernel(const float *__restrict__ w, unsigned s
         unsigned p[3];
         split3(v, p[0], p[1], p[2]);
         for (int pl = 0; pl < 3; ++pl) {
-            const size_t o = layout16 ? ((((size_t)c * 3 + pl) * 4 + t) * NP + n) * 8 + j       // [chunk][plane][tap][n][8]
-                                      : ((((size_t)(c * 2 + u) * 3 + pl) * 2 + kh) * NP + n) * 8 + j;
-            out[o] = (unsigned short)p[pl];
+            out[((((size_t)c * 3 + pl) * 4 + t) * NP + n) * 8 + j] = (unsigned short)p[pl];
         }
     }
 }
@@ -188,189 +186,11 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // ---------------------------------------------------------------------------------------------
 // forward / data-gradient kernel, split-bf16 arithmetic ("bf16x6"):
 // every f32 operand is split EXACTLY into three bf16 (hi+mid+lo) and each product is evaluated as the
-// six leading cross terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation (dropped terms are
+// six leading cross terms on the bf16 matrix cores with f32 accumulation (dropped terms are
 // <= 2^-26 relative).  Measured on gfx950 (tools/bf16x6_accuracy.hip): error vs a double reference
 // 1.4e-8*sum|a*b| mean, 1.0e-7 max at K=1120 -- slightly BELOW the f32 MFMA fma chain (1.7e-8 /
-// 1.9e-7) -- at 16/6 = 2.67x the f32 MFMA rate.  Same tile shape and LDS-DMA pipeline as
-// conv4tap_kernel; per chunk (8 channels x 4 taps) the K=32 slice is two MFMA K-steps (u = 0,1):
-// lanes 0-31 carry tap 2u, lanes 32-63 tap 2u+1, 8 channels each.
-//   A: [seg(2)][channel half(2)][320] float4 (f32 activations, split in registers)
-//   B: [u(2)][plane(3)][kh(2)][NP] x 16 B    (weights pre-split by pack_filter_split_kernel)
+// 1.9e-7) -- at 16/6 = 2.67x the f32 MFMA rate.
 // ---------------------------------------------------------------------------------------------
-// NT <= 3: cap VGPRs at 128 so that TWO workgroups share a CU (LDS 2 x 39 KB x 2): with only
-// 36 MFMAs per wave per chunk the DMA latency of a single double-buffered workgroup is exposed.
-template <int NT>
-__global__ __launch_bounds__(512, (NT <= 3 ? 4 : 2)) void conv4tap_x6_kernel(ConvArgs a, int ntiles)
-{
-    constexpr int NP = NT * 32;
-    // A: [channel half(2)][640 slots] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
-    // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
-    // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
-    // instead of 2 x 257.  Otherwise two 320-slot segments (rows y and y+1) are loaded.
-    constexpr int A_HALF = 640;
-    constexpr int A_F4 = 2 * A_HALF;
-    constexpr int B_F4 = 12 * NP;
-    constexpr int BUF_F4 = A_F4 + B_F4;
-    constexpr int N_B = B_F4 / 64;
-    constexpr int PER_WAVE = (20 + N_B + 7) / 8;      // upper bound (two-segment mode: 20 A pieces)
-    constexpr int PER_SLOT = (PER_WAVE + 1) / 2;
-    constexpr int G = 2 * NT;                   // MFMA groups (6 MFMAs each) per chunk
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *lds = reinterpret_cast<float4 *>(smem);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, kh = lane >> 5;
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-
-    // DMA addressing: a piece = wave-uniform 64-bit base (SGPRs) + one shared per-lane byte offset
-    const unsigned voff_a = (unsigned)lane * (unsigned)a.cs_in * 4u;   // A pieces: lane = position
-    const unsigned voff_b = (unsigned)lane * 16u;                      // B pieces: linear
-    const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
-    const char *in0 = reinterpret_cast<const char *>(a.in);
-    const char *wp_base = reinterpret_cast<const char *>(a.wp);
-    const size_t tile_bytes = (size_t)MMLF_TILE * a.cs_in * 4;
-    const int n_a = 2 * a.a_pieces, n_pieces = n_a + N_B;
-    // the wave index as the DMA macros see it: re-made opaque every chunk, so that the per-piece address
-    // terms derived from it are recomputed on the scalar unit instead of hoisted into (spilled) SGPRs
-    int wj = w;
-
-#define X6_DMA_PIECE(tl, c, buf, k)                                                                      \
-    do {                                                                                                 \
-        const int j_ = wj + 8 * (k);                                                                     \
-        if ((k) < PER_WAVE && j_ < n_pieces) {                                                           \
-            const char *sb_;                                                                             \
-            unsigned vo_, d_;                                                                            \
-            if (j_ < n_a) {                                                                              \
-                const int hf_ = j_ >= a.a_pieces, blk_ = j_ - hf_ * a.a_pieces;                          \
-                const int pos_ = 64 * blk_ + (blk_ >= 5 ? a.seg_delta : 0);                              \
-                sb_ = in0 + (size_t)(tl) * tile_bytes + ((size_t)pos_ * a.cs_in + 4 * hf_ + 8 * (c)) * 4; \
-                vo_ = voff_a;                                                                            \
-                d_ = (unsigned)(hf_ * A_HALF + 64 * blk_);                                               \
-            } else {                                                                                     \
-                sb_ = wp_base + ((size_t)(c) * B_F4 + 64 * (j_ - n_a)) * 16;                             \
-                vo_ = voff_b;                                                                            \
-                d_ = (unsigned)(A_F4 + 64 * (j_ - n_a));                                                 \
-            }                                                                                            \
-            d_ = lds_base + ((buf) * BUF_F4 + d_) * 16u;                                                 \
-            unsigned keep_;                                                                              \
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                       \
-                         "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"                           \
-                         : "=&s"(keep_) : "v"(vo_), "s"(sb_), "s"(d_) : "memory");                      \
-        }                                                                                                \
-    } while (0)
-#define X6_DMA_SLOT(tl, c, buf, slot)                                                                    \
-    do {                                                                                                 \
-        _Pragma("unroll") for (int k_ = 0; k_ < PER_SLOT; ++k_)                                          \
-            X6_DMA_PIECE(tl, c, buf, (slot) * PER_SLOT + k_);                                            \
-    } while (0)
-#define X6_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
-    // Persistent over tiles: the chunk pipeline runs on across tile boundaries, so the DMA of the next
-    // tile's first chunk is in flight while this tile's last chunk multiplies and its epilogue stores.
-    // XCD-aware tile order: blocks b and b+8 share an XCD (one L2).  Give every XCD a CONTIGUOUS run of
-    // tiles per sweep so that the halo rows two neighbouring tiles both read are served by one L2
-    // (speed only: any placement computes the same result).
-    const int per_xcd = (int)gridDim.x >> 3;
-    const int first_tile = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3)
-                                                : (int)blockIdx.x;
-    int tile = first_tile, c = 0;          // chunk being multiplied
-    int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
-    if (tile >= ntiles) return;
-    X6_DMA_SLOT(ntile, nc, 0, 0);
-    X6_DMA_SLOT(ntile, nc, 0, 1);
-    if (++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
-    X6_DMA_WAIT();
-    __syncthreads();
-    int buf = 0;
-
-    while (tile < ntiles) {
-        asm volatile("" : "+s"(wj));
-        const bool more = ntile < ntiles;
-        const float4 *base = lds + buf * BUF_F4;
-        const float4 *ap = base + 32 * w + i + kh;             // + u * seg_slot + half * A_HALF
-        const bf16x8 *bp = reinterpret_cast<const bf16x8 *>(base + A_F4) + kh * NP + i;   // + ((u*3+pl)*2)*NP + 32nt
-
-        // raw f32 activations of both K-steps (8 channels of this lane's tap position each)
-        float4 ra[2][2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) ra[u][hf] = ap[u * a.seg_slot + hf * A_HALF];
-        bf16x8 bq[3][3];                                       // rotating [slot][plane] weight fragments
-#pragma unroll
-        for (int g0 = 0; g0 < 2; ++g0)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                bq[g0][pl] = bp[(((g0 / NT) * 3 + pl) * 2) * NP + 32 * (g0 % NT)];
-        bf16x8 asp[2][3];                                      // [u][plane] split activations
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int u = g / NT, nt = g % NT;
-            if (g + 2 < G) {
-                const int g2 = g + 2;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    bq[g2 % 3][pl] = bp[(((g2 / NT) * 3 + pl) * 2) * NP + 32 * (g2 % NT)];
-            }
-            if (g == 0 || g == 1) {                            // split step g's activations (VALU)
-                unsigned hh[4], mm[4], ll[4];
-                split3_pair(ra[g][0].x, ra[g][0].y, hh[0], mm[0], ll[0]);
-                split3_pair(ra[g][0].z, ra[g][0].w, hh[1], mm[1], ll[1]);
-                split3_pair(ra[g][1].x, ra[g][1].y, hh[2], mm[2], ll[2]);
-                split3_pair(ra[g][1].z, ra[g][1].w, hh[3], mm[3], ll[3]);
-                const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vm = {mm[0], mm[1], mm[2], mm[3]},
-                              vl = {ll[0], ll[1], ll[2], ll[3]};
-                asp[g][0] = __builtin_bit_cast(bf16x8, vh);
-                asp[g][1] = __builtin_bit_cast(bf16x8, vm);
-                asp[g][2] = __builtin_bit_cast(bf16x8, vl);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                if (w < 4) {
-                    if (g == 0) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
-                    if (g == G / 2) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
-                } else {
-                    if (g == G / 4) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
-                    if (g == G / 2 + G / 4) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // six cross terms, small ones first
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][2], bq[g % 3][0], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][0], bq[g % 3][2], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][1], bq[g % 3][1], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][1], bq[g % 3][0], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][0], bq[g % 3][1], acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asp[u][0], bq[g % 3][0], acc[nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
-        if (++c == a.nchunk) {
-            // tile done: epilogue while the next tile's first chunk is landing
-            conv_epilogue<NT>(a, acc, (long long)tile * MMLF_TILE, w, i, kh);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-            c = 0;
-            tile += gridDim.x;
-        }
-        X6_DMA_WAIT();
-        __syncthreads();
-        buf ^= 1;
-    }
-#undef X6_DMA_PIECE
-#undef X6_DMA_SLOT
-#undef X6_DMA_WAIT
-}
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 16x16 tiling: lane (r16, q4) holds column r16 of each 16-column block and rows 16*mb + 4*q4 + r.
@@ -415,12 +235,18 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
     }
 }
 
-// 16x16x32-MFMA variant of conv4tap_x6_kernel (K = 32 = the whole 4-tap x 8-channel chunk per MFMA;
-// lane quarter q = lane>>4 carries tap q).  Weight layout [chunk][plane(3)][q(4)][NP][8 bf16].
-// VGPRs capped at 128 so that TWO workgroups share a CU (LDS 2 x 39 KB x 2): with only
-// 36 MFMAs per wave per chunk the DMA latency of a single double-buffered workgroup is exposed.
+// 512 threads = 8 waves; tile = 256 positions x 16*G output channels; wave w owns positions
+// [32w, 32w+32) x all channels as 2 x G accumulator tiles of v_mfma_f32_16x16x32_bf16 (under the
+// chip's power-limited clock this shape sustains more FLOP/s than 32x32x16: 217 vs 204 TFLOP/s
+// algorithmic at 280->280).  K is walked in chunks of 8 input channels x 4 taps = one MFMA K (lane
+// quarter q4 = lane>>4 carries tap q4), double-buffered in LDS and filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers; the copy of chunk c+1 is in flight while chunk c
+// is multiplied).  Activations stay f32 in LDS and are split in registers; weights arrive pre-split
+// from pack_filter_split_kernel as [chunk][plane(3)][tap(4)][NP][8 bf16].
+// G <= 6 (narrow layers): VGPRs capped at 128 so that TWO workgroups share a CU -- with 60 short MFMAs
+// per wave per chunk the DMA latency of a single double-buffered workgroup is exposed.
 // G = number of 16-column output blocks (NP = 16*G packed columns): 2, 5 (the 70-channel layers: 80
-// columns instead of 96) or 6.
+// columns instead of 96), 6, 7, 8 or 18.
 template <int G>
 __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
 {
@@ -1011,24 +837,27 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6_kernel(WgradArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// narrow-layer weight gradient (Cin + 1 <= 16*MB rows, Cout <= 16*NB columns; the 70-channel stream
-// layers: 80 x 80 instead of three 32-row slices x 96 columns = 1.85x the useful MFMA work).
-// One workgroup holds ALL input channels, so the gradient tile is staged and split once; wave t = tap t
-// accumulates MB x NB tiles of v_mfma_f32_16x16x32_bf16 (K = the chunk's 32 positions).
-// LDS rows are 160 B (40 dwords): the 8 position rows one half-wave touches in a transposed read then
-// start on 8 distinct multiples of 8 banks.  Lane group q4 takes positions {4q4..4q4+3, 16+4q4..}: the
-// k order is the same permutation for both operands, which a dot product does not see.
+// weight gradient on v_mfma_f32_16x16x32_bf16 (K = the chunk's 32 positions).  A workgroup owns a slice
+// of 16*MB input channels (MFMA rows, the ones row included) x 16*NB output channels and a split of the
+// positions; wave t = tap t accumulates MB x NB tiles.
+//  <5,5>: the 70-channel stream layers in ONE slice, 80 x 80 (three 32-row slices x 96 columns would
+//         be 1.85x the useful MFMA work), gradient tile staged and split once per chunk;
+//  <2,18>: 32-channel slices x 288 columns for the 280-wide layers.
+// LDS rows are padded to an odd multiple of 32 B: the 8 position rows one half-wave touches in a
+// transposed read then start on 8 distinct multiples of 8 banks (conflict-free).  Lane group q4 takes
+// positions {4q4..4q4+3, 16+4q4..}: the same k permutation for both operands, which a dot product
+// does not see.
 // ---------------------------------------------------------------------------------------------
 template <int MB, int NB>
 __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
 {
-    static_assert(MB <= 5 && NB <= 5, "LDS row holds 80 channels");
-    constexpr int ROWB = 160;
-    constexpr int A_PLANE = 34 * ROWB;            // per (seg, plane)
+    constexpr int ROWA = 32 * (MB | 1), ROWG = 32 * (NB | 1);   // bytes per position row
+    constexpr int A_PLANE = 34 * ROWA;                          // per (seg, plane)
     constexpr int A_BYTES = 6 * A_PLANE;
-    constexpr int G_PLANE = WG_KQ * ROWB;
-    constexpr int FA = 4 * MB, FG = 4 * NB;       // float4 per staged row
+    constexpr int G_PLANE = WG_KQ * ROWG;
+    constexpr int FA = 4 * MB, FG = 4 * NB;                     // float4 per staged row
     constexpr int NA = (66 * FA + 255) / 256, NG = (WG_KQ * FG + 255) / 256;
+    constexpr bool HOLD_G = NB <= 5;    // few columns: keep all gradient fragments, stream the activations
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *As = smem;
     char *Gs = smem + A_BYTES;
@@ -1036,7 +865,13 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63, t = tid >> 6;
     const int r16 = lane & 15, q4 = lane >> 4;
-    const int split = blockIdx.x;
+    // blocks b and b+8 share an XCD: the slices of one position split sit on one L2 and share its g reads
+    const int b = blockIdx.x;
+    const int kk = b >> 3;
+    const int slice = kk % a.nslice;
+    const int split = (kk / a.nslice) * 8 + (b & 7);
+    if (split >= a.nsplit) return;
+    const int ci0 = slice * 16 * MB;
     int c_begin = split * a.chunks_per_split;
     int c_end = c_begin + a.chunks_per_split;
     if (c_end > a.nchunks) c_end = a.nchunks;
@@ -1057,9 +892,10 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
             const int idx = tid + 256 * j;                                                                  \
             const int row = idx / FA, f = idx - row * FA;                                                   \
             const int seg = row >= 33, pix = row - 33 * seg;                                                \
+            const int ch = ci0 + 4 * f;                                                                     \
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
-            if (idx < 66 * FA && 4 * f < a.cs_in)                                                           \
-                v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + 4 * f); \
+            if (idx < 66 * FA && ch < a.cs_in)                                                              \
+                v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
             ra[j] = v;                                                                                      \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
@@ -1078,28 +914,37 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
             if (idx < 66 * FA) {                                                                            \
                 const int row = idx / FA, f = idx - row * FA;                                               \
                 const int seg = row >= 33, pix = row - 33 * seg;                                            \
-                float4 v = ra[j];                                                                           \
-                const int ch = 4 * f;     /* ones row -> bias gradient */                                   \
+                float4 v = ra[j];         /* ones row (bias gradient): patched here, not at load time, */ \
+                const int ch = ci0 + 4 * f; /* so that the global loads issue back to back               */ \
                 if (ch == a.cin) v.x = 1.f;                                                                 \
                 if (ch + 1 == a.cin) v.y = 1.f;                                                             \
                 if (ch + 2 == a.cin) v.z = 1.f;                                                             \
                 if (ch + 3 == a.cin) v.w = 1.f;                                                             \
-                split_store4(v, As + seg * 3 * A_PLANE + pix * ROWB + 8 * f, A_PLANE);                      \
+                split_store4(v, As + seg * 3 * A_PLANE + pix * ROWA + 8 * f, A_PLANE);                      \
             }                                                                                               \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
             const int idx = tid + 256 * j;                                                                  \
             if (idx < WG_KQ * FG) {                                                                         \
                 const int row = idx / FG, f = idx - row * FG;                                               \
-                split_store4(rg[j], Gs + row * ROWB + 8 * f, G_PLANE);                                      \
+                split_store4(rg[j], Gs + row * ROWG + 8 * f, G_PLANE);                                      \
             }                                                                                               \
         }                                                                                                   \
+    } while (0)
+#define WN_MFMA6(af, gf, c)                                                                                 \
+    do {                                                                                                    \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], gf[0], c, 0, 0, 0);                              \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[2], c, 0, 0, 0);                              \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[1], c, 0, 0, 0);                              \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[0], c, 0, 0, 0);                              \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[1], c, 0, 0, 0);                              \
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[0], c, 0, 0, 0);                              \
     } while (0)
 
     // transposed-read geometry: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
     const int tq = (lane & 15) >> 2, tp = lane & 3;
-    const char *a_lane = As + (t >> 1) * 3 * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWB + 8 * tp;
-    const char *g_lane = Gs + (4 * q4 + tq) * ROWB + 8 * tp;
+    const char *a_lane = As + (t >> 1) * 3 * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWA + 8 * tp;
+    const char *g_lane = Gs + (4 * q4 + tq) * ROWG + 8 * tp;
 
     if (c_begin < c_end) {
         WN_GLOAD(c_begin);
@@ -1107,24 +952,33 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
             WN_LSTORE();
             __syncthreads();
             if (c + 1 < c_end) WN_GLOAD(c + 1);
-            bf16x8 gf[NB][3];
+            if constexpr (HOLD_G) {
+                bf16x8 gf[NB][3];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) gf[nb][pl] = tr_frag(g_lane + pl * G_PLANE + 32 * nb, 4 * ROWB);
+                    for (int pl = 0; pl < 3; ++pl) gf[nb][pl] = tr_frag(g_lane + pl * G_PLANE + 32 * nb, 4 * ROWG);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                bf16x8 af[3];
+                for (int mb = 0; mb < MB; ++mb) {
+                    bf16x8 af[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[pl] = tr_frag(a_lane + pl * A_PLANE + 32 * mb, 4 * ROWB);
+                    for (int pl = 0; pl < 3; ++pl) af[pl] = tr_frag(a_lane + pl * A_PLANE + 32 * mb, 4 * ROWA);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) WN_MFMA6(af, gf[nb], acc[mb][nb]);
+                }
+            } else {
+                bf16x8 af[MB][3];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) af[mb][pl] = tr_frag(a_lane + pl * A_PLANE + 32 * mb, 4 * ROWA);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], gf[nb][0], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[nb][2], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[nb][1], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[nb][0], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[nb][1], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[nb][0], acc[mb][nb], 0, 0, 0);
+                    bf16x8 gf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) gf[pl] = tr_frag(g_lane + pl * G_PLANE + 32 * nb, 4 * ROWG);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) WN_MFMA6(af[mb], gf, acc[mb][nb]);
                 }
             }
             __syncthreads();
@@ -1132,12 +986,167 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
     }
 #undef WN_GLOAD
 #undef WN_LSTORE
-    constexpr int CIP = 16 * MB, NP = 16 * NB;
-    float *pp = a.part + (size_t)(split * 4 + t) * CIP * NP;
+#undef WN_MFMA6
+    constexpr int NP = 16 * NB;
+    const int CIP = a.nslice * 16 * MB;
+    float *pp = a.part + ((size_t)(split * 4 + t) * CIP + ci0) * NP;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pp[(size_t)(16 * mb + 4 * q4 + r) * NP + 16 * nb + r16] = acc[mb][nb][r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// wide-layer weight gradient (Cout <= 288): 512 threads = 8 waves, wave w = (tap w&3, column half w>>2).
+// A workgroup owns a slice of 16*MB input channels x all 288 columns and a split of the positions; the
+// LDS image is DOUBLE-buffered: while chunk c is multiplied, the registers holding chunk c+1 (loaded
+// from global memory one iteration earlier) are split and stored into the other buffer between the
+// MFMAs, and chunk c+2's loads are issued.  One barrier per chunk, no phase in which the matrix
+// cores wait for staging.  155.9 KB of LDS: one workgroup per CU.
+// ---------------------------------------------------------------------------------------------
+template <int MB, int NBH>
+__global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
+{
+    constexpr int NB = 2 * NBH;
+    constexpr int ROWA = 32 * (MB | 1), ROWG = 32 * (NB | 1);
+    constexpr int A_PLANE = 34 * ROWA;
+    constexpr int A_BYTES = 6 * A_PLANE;
+    constexpr int G_PLANE = WG_KQ * ROWG;
+    constexpr int BUF_BYTES = A_BYTES + 3 * G_PLANE;
+    constexpr int FA = 4 * MB, FG = 4 * NB;
+    constexpr int NA = (66 * FA + 511) / 512, NG = (WG_KQ * FG + 511) / 512;
+    static_assert(2 * BUF_BYTES <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = w & 3, h = w >> 2;
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int b = blockIdx.x;
+    const int kk = b >> 3;
+    const int slice = kk % a.nslice;
+    const int split = (kk / a.nslice) * 8 + (b & 7);
+    if (split >= a.nsplit) return;
+    const int ci0 = slice * 16 * MB;
+    const int c_begin = split * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > a.nchunks) c_end = a.nchunks;
+
+    f32x4 acc[MB][NBH];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBH; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
+
+    float4 ra[NA], rg[NG];
+#define WW_GLOAD(c)                                                                                         \
+    do {                                                                                                    \
+        const long long Qc = (long long)(c) * WG_KQ;                                                        \
+        _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
+            const int idx = tid + 512 * j;                                                                  \
+            const int row = idx / FA, f = idx - row * FA;                                                   \
+            const int seg = row >= 33, pix = row - 33 * seg;                                                \
+            const int ch = ci0 + 4 * f;                                                                     \
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+            if (idx < 66 * FA && ch < a.cs_in)                                                              \
+                v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
+            ra[j] = v;                                                                                      \
+        }                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
+            const int idx = tid + 512 * j;                                                                  \
+            const int row = idx / FG, f = idx - row * FG;                                                   \
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+            if (idx < WG_KQ * FG && 4 * f < a.cs_g)                                                         \
+                v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + 4 * f); \
+            rg[j] = v;                                                                                      \
+        }                                                                                                   \
+    } while (0)
+#define WW_STORE_A(j, dst)                                                                                  \
+    do {                                                                                                    \
+        const int idx = tid + 512 * (j);                                                                    \
+        if (idx < 66 * FA) {                                                                                \
+            const int row = idx / FA, f = idx - row * FA;                                                   \
+            const int seg = row >= 33, pix = row - 33 * seg;                                                \
+            float4 v = ra[j];             /* ones row -> bias gradient */                                   \
+            const int ch = ci0 + 4 * f;                                                                     \
+            if (ch == a.cin) v.x = 1.f;                                                                     \
+            if (ch + 1 == a.cin) v.y = 1.f;                                                                 \
+            if (ch + 2 == a.cin) v.z = 1.f;                                                                 \
+            if (ch + 3 == a.cin) v.w = 1.f;                                                                 \
+            split_store4(v, (dst) + seg * 3 * A_PLANE + pix * ROWA + 8 * f, A_PLANE);                       \
+        }                                                                                                   \
+    } while (0)
+#define WW_STORE_G(j, dst)                                                                                  \
+    do {                                                                                                    \
+        const int idx = tid + 512 * (j);                                                                    \
+        if (idx < WG_KQ * FG) {                                                                             \
+            const int row = idx / FG, f = idx - row * FG;                                                   \
+            split_store4(rg[j], (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);                             \
+        }                                                                                                   \
+    } while (0)
+
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int a_off = (t >> 1) * 3 * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWA + 8 * tp;
+    const int g_off = A_BYTES + (4 * q4 + tq) * ROWG + 8 * tp + 32 * NBH * h;
+
+    if (c_begin < c_end) {
+        WW_GLOAD(c_begin);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) WW_STORE_A(j, smem);
+#pragma unroll
+        for (int j = 0; j < NG; ++j) WW_STORE_G(j, smem);
+        if (c_begin + 1 < c_end) WW_GLOAD(c_begin + 1);
+        __syncthreads();
+        int buf = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            const char *cur = smem + buf * BUF_BYTES;
+            char *nxt = smem + (buf ^ 1) * BUF_BYTES;
+            const bool stage = c + 1 < c_end;        // registers hold chunk c+1: store it beside the MFMAs
+            bf16x8 af[MB][3];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) af[mb][pl] = tr_frag(cur + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);
+#pragma unroll
+            for (int nb = 0; nb < NBH; ++nb) {
+                bf16x8 gf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) gf[pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * nb, 4 * ROWG);
+                if (stage) {
+                    if (nb < NA) WW_STORE_A(nb < NA ? nb : 0, nxt);
+                    else if (nb - NA < NG) WW_STORE_G(nb - NA < NG ? nb - NA : 0, nxt);
+                }
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][2], gf[0], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][0], gf[2], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][1], gf[1], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][1], gf[0], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][0], gf[1], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][0], gf[0], acc[mb][nb], 0, 0, 0);
+                }
+            }
+            static_assert(NA + NG <= NBH, "one staging piece per column block");
+            if (c + 2 < c_end) WW_GLOAD(c + 2);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+#undef WW_GLOAD
+#undef WW_STORE_A
+#undef WW_STORE_G
+    constexpr int NP = 16 * NB;
+    const int CIP = a.nslice * 16 * MB;
+    float *pp = a.part + ((size_t)(split * 4 + t) * CIP + ci0) * NP + 16 * NBH * h;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) pp[(size_t)(16 * mb + 4 * q4 + r) * NP + 16 * nb + r16] = acc[mb][nb][r];
 }
@@ -1182,22 +1191,37 @@ extern "C" int64_t mmlf_packed_filter_floats(int K, int N)
     return (int64_t)((K + 7) / 8) * 4 * 2 * (nt * 32) * 4;
 }
 
-// split-arithmetic narrow kernel: 16-row blocks MB (Cin + ones row) when the layer fits 80 x 80, else 0
-static inline int wgrad_narrow_mb(int Cin, int Cout)
+// split-arithmetic kernel configuration for a layer: MB 16-row blocks of input channels (+ ones row) per
+// slice, NB 16-column blocks of output channels, and the (slice x position-split) grid
+struct Wgrad16Cfg { int mb, nb, nslice, nsplit; };
+static inline bool wgrad16_cfg(int Cin, int Cout, Wgrad16Cfg *c)
 {
-    if (Cout <= 32 || Cout > 80 || Cin + 1 > 80) return 0;
-    return Cin + 1 <= 32 ? 2 : 5;
+    if (Cout <= 0 || Cout > 288) return false;
+    c->nb = Cout <= 32 ? 2 : Cout <= 80 ? 5 : Cout <= 128 ? 8 : 18;
+    if (c->nb == 18) {           // wgrad4tap_x6w_kernel: one 512-thread workgroup per CU, three even rounds
+        c->mb = 3;
+        c->nslice = (Cin + 1 + 47) / 48;
+        c->nsplit = (768 / c->nslice + 7) / 8 * 8;
+        if (c->nsplit < 8) c->nsplit = 8;
+    } else {                     // wgrad4tap_x6n_kernel: two 256-thread workgroups per CU
+        c->mb = (c->nb <= 5 && Cin + 1 > 32 && Cin + 1 <= 80) ? 5 : 2;
+        c->nslice = (Cin + 1 + 16 * c->mb - 1) / (16 * c->mb);
+        c->nsplit = wgrad_nsplit(c->nslice);
+    }
+    return true;
 }
-#define WGRAD_NARROW_NSPLIT 512   // two 256-thread blocks per CU on 256 CUs
 
 extern "C" int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout)
 {
     const int nt = pick_nt(Cout);
     if (nt < 0) return -1;
     const int nslice = (Cin + 1 + 31) / 32;
-    int64_t n = (int64_t)wgrad_nsplit(nslice) * 4 * (nslice * 32) * (nt * 32);
-    const int mb = wgrad_narrow_mb(Cin, Cout);
-    if (mb && n < (int64_t)WGRAD_NARROW_NSPLIT * 4 * (16 * mb) * 80) n = (int64_t)WGRAD_NARROW_NSPLIT * 4 * (16 * mb) * 80;
+    int64_t n = (int64_t)wgrad_nsplit(nslice) * 4 * (nslice * 32) * (nt * 32);          // exact-f32 kernel
+    Wgrad16Cfg c;
+    if (wgrad16_cfg(Cin, Cout, &c)) {                                                    // split kernel
+        const int64_t m = (int64_t)c.nsplit * 4 * (c.nslice * 16 * c.mb) * (16 * c.nb);
+        if (m > n) n = m;
+    }
     return n;
 }
 
@@ -1281,10 +1305,29 @@ static int launch_wgrad(const WgradArgs &a, hipStream_t st, int split_bf16)
 }
 
 template <int MB, int NB>
-static int launch_wgrad_narrow(const WgradArgs &a, hipStream_t st)
+static int launch_wgrad16(const WgradArgs &a, hipStream_t st)
 {
-    constexpr size_t lds = 6 * 34 * 160 + 3 * WG_KQ * 160;
-    hipLaunchKernelGGL((wgrad4tap_x6n_kernel<MB, NB>), dim3((unsigned)a.nsplit), dim3(256), lds, st, a);
+    constexpr size_t lds = 6 * 34 * 32 * (MB | 1) + 3 * WG_KQ * 32 * (NB | 1);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6n_kernel<MB, NB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((wgrad4tap_x6n_kernel<MB, NB>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(256), lds, st, a);
+    return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
+}
+
+static int launch_wgrad_wide(const WgradArgs &a, hipStream_t st)
+{
+    constexpr size_t lds = 2 * (6 * 34 * 32 * (3 | 1) + 3 * WG_KQ * 32 * (18 | 1));
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6w_kernel<3, 9>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((wgrad4tap_x6w_kernel<3, 9>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(512), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
 }
 
@@ -1329,16 +1372,23 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
     a.chunks_per_split = (a.nchunks + a.nsplit - 1) / a.nsplit;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    const int mb = split_bf16 ? wgrad_narrow_mb(Cin, Cout) : 0;
-    if (mb) {
-        a.nslice = 1;
-        a.nsplit = WGRAD_NARROW_NSPLIT;
+    Wgrad16Cfg c;
+    if (split_bf16 && !getenv("MMLF_WGRAD_OLD") && wgrad16_cfg(Cin, Cout, &c)) {
+        a.nslice = c.nslice;
+        a.nsplit = c.nsplit;
         a.chunks_per_split = (a.nchunks + a.nsplit - 1) / a.nsplit;
-        rc = mb == 2 ? launch_wgrad_narrow<2, 5>(a, st) : launch_wgrad_narrow<5, 5>(a, st);
+        switch (10 * c.mb + c.nb) {
+        case 22: rc = launch_wgrad16<2, 2>(a, st); break;
+        case 52: rc = launch_wgrad16<5, 2>(a, st); break;
+        case 25: rc = launch_wgrad16<2, 5>(a, st); break;
+        case 55: rc = launch_wgrad16<5, 5>(a, st); break;
+        case 28: rc = launch_wgrad16<2, 8>(a, st); break;
+        default: rc = launch_wgrad_wide(a, st); break;
+        }
         if (rc) return rc;
         const int total = 4 * (Cin + 1) * Cout;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw, gb, Cin,
-                           Cout, 16 * mb, 80, a.nsplit, variant, accumulate);
+                           Cout, a.nslice * 16 * c.mb, 16 * c.nb, a.nsplit, variant, accumulate);
         return mmlf_launch_status("mmlf_conv2x2_wgrad(reduce)");
     }
     switch (nt) {
@@ -1388,7 +1438,7 @@ extern "C" int mmlf_pack_filter_split(const float *w, void *packed, int Cout, in
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_filter_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                       (unsigned short *)packed, Cout, Cin, variant, dgrad, nchunk, NP, 1);
+                       (unsigned short *)packed, Cout, Cin, variant, dgrad, nchunk, NP);
     return mmlf_launch_status("mmlf_pack_filter_split");
 }
 
@@ -1405,23 +1455,7 @@ static int device_cus()
     return cus;
 }
 
-// persistent launches: one workgroup per CU (two for the narrow variant), each walks tiles b, b+grid, ...
-template <int NT>
-static int launch_conv_x6(const ConvArgs &a, long long ntiles, hipStream_t st)
-{
-    constexpr size_t lds = 2 * (2 * 640 + 12 * NT * 32) * sizeof(float4);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6_kernel<NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    long long grid = device_cus();
-    if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(conv4tap_x6_kernel<NT>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
-    return mmlf_launch_status("mmlf_conv2x2_split");
-}
-
+// persistent launches: one workgroup per CU (two for the narrow variants), each walks tiles b, b+grid, ...
 template <int G>
 static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
