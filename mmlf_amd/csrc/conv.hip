@@ -400,8 +400,10 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
+        // the next chunk's DMA pieces must have landed before the barrier; at a tile end wait for them
+        // BEFORE the epilogue, so that its stores (same counter) stay in flight across the barrier
+        X6_DMA_WAIT();
         if (++c == a.nchunk) {
-            // tile done: epilogue while the next tile's first chunk is landing
             conv_epilogue16<G>(a, acc, (long long)tile * MMLF_TILE, w, r16, q4);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -412,7 +414,6 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
             c = 0;
             tile += gridDim.x;
         }
-        X6_DMA_WAIT();
         __syncthreads();
         buf ^= 1;
     }
@@ -679,12 +680,11 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_kernel(WgradArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight-gradient kernel, split-bf16 arithmetic (same decomposition as wgrad4tap_kernel).
-// K = positions: v_mfma_f32_32x32x16_bf16 wants 8 consecutive positions per lane for a fixed
-// channel, i.e. the transposed image of the NHWC tiles.  The tiles are split into three bf16 planes
-// while they are staged (registers -> LDS, row-major [position][channel] like global memory) and the
-// fragments are fetched with ds_read_b64_tr_b16, gfx950's transposing LDS read:
-//   A planes: [seg(2)][plane(3)][34 positions][32 ci] bf16      G planes: [plane(3)][32 positions][NP co] bf16
+// weight-gradient kernels, split-bf16 arithmetic (same decomposition as wgrad4tap_kernel).
+// K = positions: the bf16 MFMA wants 8 consecutive positions per lane for a fixed channel, i.e. the
+// transposed image of the NHWC tiles.  The tiles are split into three bf16 planes while they are staged
+// (registers -> LDS, row-major [position][channel] like global memory) and the fragments are fetched
+// with ds_read_b64_tr_b16, gfx950's transposing LDS read.
 // ---------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
@@ -705,135 +705,6 @@ __device__ __forceinline__ void split_store4(float4 v, char *p0, int plane_strid
     *reinterpret_cast<uint2 *>(p0) = make_uint2(h0, h1);
     *reinterpret_cast<uint2 *>(p0 + plane_stride_bytes) = make_uint2(m0, m1);
     *reinterpret_cast<uint2 *>(p0 + 2 * plane_stride_bytes) = make_uint2(l0, l1);
-}
-
-template <int NT>
-__global__ __launch_bounds__(256, 2) void wgrad4tap_x6_kernel(WgradArgs a)
-{
-    constexpr int NP = NT * 32;
-    constexpr int A_ROW = 64;                     // bytes per position row (32 ci bf16)
-    constexpr int A_PLANE = 34 * A_ROW;           // per (seg, plane)
-    constexpr int A_BYTES = 6 * A_PLANE;
-    constexpr int G_ROW = 2 * NP;                 // bytes per position row
-    constexpr int G_PLANE = WG_KQ * G_ROW;
-    constexpr int NA = 3;
-    constexpr int NG = NT;                        // float4 per thread of the gradient tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *As = smem;
-    char *Gs = smem + A_BYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, t = tid >> 6;
-    const int kh = lane >> 5;
-    const int b = blockIdx.x;
-    const int kk = b >> 3;
-    const int slice = kk % a.nslice;
-    const int split = (kk / a.nslice) * 8 + (b & 7);
-    if (split >= a.nsplit) return;
-    const int ci0 = slice * 32;
-    int c_begin = split * a.chunks_per_split;
-    int c_end = c_begin + a.chunks_per_split;
-    if (c_end > a.nchunks) c_end = a.nchunks;
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-
-    float4 ra[NA], rg[NG];
-#define WX6_GLOAD(c)                                                                                        \
-    do {                                                                                                    \
-        const long long Qc = (long long)(c) * WG_KQ;                                                        \
-        _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
-            const int idx = tid + 256 * j;                                                                  \
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
-            if (idx < 528) {                                                                                \
-                const int row = idx >> 3, f = idx & 7;                                                      \
-                const int seg = row >= 33, pix = row - 33 * seg;                                            \
-                const int ch = ci0 + 4 * f;                                                                 \
-                if (ch < a.cs_in)                                                                           \
-                    v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
-            }                                                                                               \
-            ra[j] = v;                                                                                      \
-        }                                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
-            const int idx = tid + 256 * j;                                                                  \
-            const int row = idx / (NP / 4), f = idx - row * (NP / 4);                                       \
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
-            if (4 * f < a.cs_g)                                                                             \
-                v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + 4 * f); \
-            rg[j] = v;                                                                                      \
-        }                                                                                                   \
-    } while (0)
-#define WX6_LSTORE()                                                                                        \
-    do {                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
-            const int idx = tid + 256 * j;                                                                  \
-            if (idx < 528) {                                                                                \
-                const int row = idx >> 3, f = idx & 7;                                                      \
-                const int seg = row >= 33, pix = row - 33 * seg;                                            \
-                float4 v = ra[j];         /* ones row (bias gradient): patched here, not at load time, */ \
-                const int ch = ci0 + 4 * f; /* so that the global loads issue back to back               */ \
-                if (ch == a.cin) v.x = 1.f;                                                                 \
-                if (ch + 1 == a.cin) v.y = 1.f;                                                             \
-                if (ch + 2 == a.cin) v.z = 1.f;                                                             \
-                if (ch + 3 == a.cin) v.w = 1.f;                                                             \
-                split_store4(v, As + seg * 3 * A_PLANE + pix * A_ROW + 8 * f, A_PLANE);                     \
-            }                                                                                               \
-        }                                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
-            const int idx = tid + 256 * j;                                                                  \
-            const int row = idx / (NP / 4), f = idx - row * (NP / 4);                                       \
-            split_store4(rg[j], Gs + row * G_ROW + 8 * f, G_PLANE);                                         \
-        }                                                                                                   \
-    } while (0)
-
-    // transposed-read lane geometry: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
-    const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
-    const char *a_lane = As + (t >> 1) * 3 * A_PLANE + ((t & 1) + 8 * kh + tq) * A_ROW + (16 * tg + 4 * tp) * 2;
-    const char *g_lane = Gs + (8 * kh + tq) * G_ROW + (16 * tg + 4 * tp) * 2;
-
-    if (c_begin < c_end) {
-        WX6_GLOAD(c_begin);
-        for (int c = c_begin; c < c_end; ++c) {
-            WX6_LSTORE();
-            __syncthreads();
-            if (c + 1 < c_end) WX6_GLOAD(c + 1);
-#pragma unroll
-            for (int u = 0; u < WG_KQ / 16; ++u) {
-                bf16x8 af[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[pl] = tr_frag(a_lane + pl * A_PLANE + 16 * u * A_ROW, A_ROW);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    bf16x8 gf[3];
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        gf[pl] = tr_frag(g_lane + pl * G_PLANE + 16 * u * G_ROW + 64 * nt, G_ROW);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], gf[0], acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], gf[2], acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], gf[1], acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], gf[0], acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], gf[1], acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], gf[0], acc[nt], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-        }
-    }
-#undef WX6_GLOAD
-#undef WX6_LSTORE
-    const int i = lane & 31;
-    const int CIP = a.nslice * 32;
-    float *pp = a.part + ((size_t)(split * 4 + t) * CIP + ci0) * NP;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            pp[(size_t)row * NP + 32 * nt + i] = acc[nt][r];
-        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1286,19 +1157,8 @@ extern "C" int mmlf_conv2x2(const float *in, int cs_in, int K, const float *pack
 }
 
 template <int NT>
-static int launch_wgrad(const WgradArgs &a, hipStream_t st, int split_bf16)
+static int launch_wgrad(const WgradArgs &a, hipStream_t st)
 {
-    if (split_bf16) {
-        constexpr size_t lds = 6 * 34 * 64 + 3 * WG_KQ * 2 * NT * 32;
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6_kernel<NT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL(wgrad4tap_x6_kernel<NT>, dim3((unsigned)(a.nslice * a.nsplit)), dim3(256), lds, st, a);
-        return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
-    }
     constexpr size_t lds = (2 * 33 * 32 + WG_KQ * NT * 32) * sizeof(float);
     hipLaunchKernelGGL(wgrad4tap_kernel<NT>, dim3((unsigned)(a.nslice * a.nsplit)), dim3(256), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad");
@@ -1373,7 +1233,7 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
     hipStream_t st = (hipStream_t)stream;
     int rc;
     Wgrad16Cfg c;
-    if (split_bf16 && !getenv("MMLF_WGRAD_OLD") && wgrad16_cfg(Cin, Cout, &c)) {
+    if (split_bf16 && wgrad16_cfg(Cin, Cout, &c)) {
         a.nslice = c.nslice;
         a.nsplit = c.nsplit;
         a.chunks_per_split = (a.nchunks + a.nsplit - 1) / a.nsplit;
@@ -1392,10 +1252,10 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
         return mmlf_launch_status("mmlf_conv2x2_wgrad(reduce)");
     }
     switch (nt) {
-    case 1: rc = launch_wgrad<1>(a, st, split_bf16); break;
-    case 3: rc = launch_wgrad<3>(a, st, split_bf16); break;
-    case 4: rc = launch_wgrad<4>(a, st, split_bf16); break;
-    default: rc = launch_wgrad<9>(a, st, split_bf16); break;
+    case 1: rc = launch_wgrad<1>(a, st); break;
+    case 3: rc = launch_wgrad<3>(a, st); break;
+    case 4: rc = launch_wgrad<4>(a, st); break;
+    default: rc = launch_wgrad<9>(a, st); break;
     }
     if (rc) return rc;
     const int total = 4 * (Cin + 1) * Cout;
