@@ -69,7 +69,7 @@ int mmlf_conv2x2(const float *in, int cs_in, int K, const float *packed, const f
 
 /* Split-precision variant of mmlf_pack_filter / mmlf_conv2x2 (same arguments and semantics).
  * Every f32 operand is split exactly into three bf16 (hi+mid+lo); each product is evaluated as its six
- * leading cross terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation.  Measured error vs a double
+ * leading cross terms on v_mfma_f32_16x16x32_bf16 with f32 accumulation.  Measured error vs a double
  * reference is at (slightly below) the level of the f32 MFMA fma chain, at 2.67x its rate
  * (DESIGN.md section 4.4).  `packed` holds mmlf_packed_filter_split_bytes(K, N) bytes. */
 int64_t mmlf_packed_filter_split_bytes(int K, int N);
@@ -166,6 +166,28 @@ int mmlf_shift_views(const float *h, const float *v, const float *i, const float
  * mean, logvar (arg-min logvar member), posterior (B,S,H,W) = mean of S Laplacians on grid[S]. */
 int mmlf_ensamble_reduce(const float *means, const float *logvars, const float *grid, float *mean,
                          float *logvar, float *posterior, int S, int B, int H, int W, void *stream);
+
+/* Training patch pipeline: the transform chain the reference's training CLI
+ * composes (mmlf/train/cli.py:72-91) -- RandomDownSampling, RandomShift, RandomCrop + CenterCrop,
+ * RandomRotate, RedistColor, Brightness (mmlf/data/hci4d.py:483-510, 907-990, 532-575, 1041-1071,
+ * 698-715, 773-782) -- on scenes cached in device memory, one gather per output pixel.
+ *   stacks (S,4,V,3,Hf,Wf), center (S,3,Hf,Wf), gt (S,Hf,Wf), mpi (S,P,5,Hf,Wf) or NULL with P=0,
+ *   mask (S,Hf,Wf) int32.  Per sample b (parameters drawn on the host in the reference's call order):
+ *   iparam[b] = {scene, factor, y0, x0, rot, flags (1 shift | 2 colour | 4 brightness), 0, 0},
+ *   fparam[b] = {float(factor), disp, brightness, 0}, tab_s/tab_w[b][view] as mmlf_shift_views,
+ *   mat[b] = 3x3 RedistColor matrix (double), rot_src[rot][stack][view] = source stack*V + view after
+ *   `rot` Rotate90 steps.  Outputs: o_stacks (4,B,V,3,ps,ps), o_center (B,3,ps,ps), o_gt (B,ps,ps),
+ *   o_mpi (B,P,5,ps,ps), o_mask (B,ps,ps) (the reference does not rotate the mask, hci4d.py:1056);
+ *   mean_sum[b] (zeroed by the caller) accumulates the sum of the horizontal stack for Contrast. */
+int mmlf_patch_gather(const float *stacks, const float *center, const float *gt, const float *mpi,
+                      const int32_t *mask, int S, int V, int P, int Hf, int Wf, const int32_t *iparam,
+                      const float *fparam, const int32_t *tab_s, const float *tab_w, const double *mat,
+                      const int32_t *rot_src, float *o_stacks, float *o_center, float *o_gt, float *o_mpi,
+                      int32_t *o_mask, double *mean_sum, int B, int ps, void *stream);
+/* Contrast (hci4d.py:740-751) in place on o_stacks / o_center: x*alpha[b][0] + mean_b*alpha[b][1] with
+ * alpha[b] = {float(alpha), float(1 - alpha)} and mean_b = mean_sum[b] / (V*3*ps*ps). */
+int mmlf_patch_contrast(float *o_stacks, float *o_center, const double *mean_sum, const float *alpha,
+                        int B, int V, int ps, void *stream);
 
 #ifdef __cplusplus
 }

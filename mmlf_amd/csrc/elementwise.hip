@@ -541,6 +541,177 @@ __global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ h,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Training patch pipeline: the transform chain of reference train/cli.py:72-91 on scenes cached in HBM,
+// fused into one gather per output pixel.  Per sample (host-drawn parameters, reference call order):
+// DownSampling f (hci4d.py:483-510) -> Shift disp (:907-990) -> Crop at (y0,x0) (:532-575; RandomCrop +
+// CenterCrop collapse to one offset) -> rot x Rotate90 (:1041-1071) -> RedistColor (:698-715) ->
+// Brightness (:773-782); Contrast (:740-751) needs the mean of the finished horizontal stack and runs
+// as a second pass.
+// ---------------------------------------------------------------------------------------------
+struct PatchSample {
+    int scene, f, y0, x0, rot, flags;      // flags: 1 = shift, 2 = colour, 4 = brightness
+    float fdiv, disp, bright;
+};
+#define PATCH_IP 8
+#define PATCH_FP 4
+
+__device__ __forceinline__ PatchSample patch_sample(const int32_t *ip, const float *fp, int b)
+{
+    PatchSample p;
+    p.scene = ip[b * PATCH_IP + 0]; p.f = ip[b * PATCH_IP + 1]; p.y0 = ip[b * PATCH_IP + 2];
+    p.x0 = ip[b * PATCH_IP + 3]; p.rot = ip[b * PATCH_IP + 4]; p.flags = ip[b * PATCH_IP + 5];
+    p.fdiv = fp[b * PATCH_FP + 0]; p.disp = fp[b * PATCH_FP + 1]; p.bright = fp[b * PATCH_FP + 2];
+    return p;
+}
+
+// patch coordinates before `rot` applications of out[y][x] = in[x][ps-1-y] (flip(transpose(.)), hci4d.py:1058-1061)
+__device__ __forceinline__ void unrotate(int rot, int ps, int &y, int &x)
+{
+    for (int k = 0; k < rot; ++k) {
+        const int t = y;
+        y = x;
+        x = ps - 1 - t;
+    }
+}
+
+// RedistColor: float64 matrix entry x float32 image, rounded to float32 after every step (numpy >= 2)
+__device__ __forceinline__ void redist_color(const double *m, float &c0, float &c1, float &c2)
+{
+    const double s0 = c0, s1 = c1, s2 = c2;
+    float o[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float a = (float)__dmul_rn(m[3 * r], s0);
+        a = (float)__dadd_rn((double)a, __dmul_rn(m[3 * r + 1], s1));
+        a = (float)__dadd_rn((double)a, __dmul_rn(m[3 * r + 2], s2));
+        o[r] = a;
+    }
+    c0 = o[0]; c1 = o[1]; c2 = o[2];
+}
+
+// grid: (B * 4 stacks * V views * ps rows); threads over x.  out: (4, B, V, 3, ps, ps)
+__global__ __launch_bounds__(128) void patch_stacks_kernel(
+    const float *__restrict__ stacks, const int32_t *__restrict__ ip, const float *__restrict__ fp,
+    const int32_t *__restrict__ tab_s, const float *__restrict__ tab_w, const double *__restrict__ mat,
+    const int32_t *__restrict__ rot_src, float *__restrict__ out, double *__restrict__ mean_sum, int B, int V,
+    int Hf, int Wf, int ps)
+{
+    int r = blockIdx.x;
+    const int y = r % ps; r /= ps;
+    const int n = r % V; r /= V;
+    const int so = r % 4;
+    const int b = r / 4;
+    const PatchSample p = patch_sample(ip, fp, b);
+    const int src = rot_src[(p.rot * 4 + so) * V + n];
+    const int ss = src / V, sn = src % V;                 // stack and view the pixel comes from
+    const int Hd = (Hf + p.f - 1) / p.f, Wd = (Wf + p.f - 1) / p.f;
+    ShiftTab t;
+    t.s0 = tab_s[2 * (b * V + sn)]; t.s1 = tab_s[2 * (b * V + sn) + 1];
+    t.w0 = tab_w[2 * (b * V + sn)]; t.w1 = tab_w[2 * (b * V + sn) + 1];
+    const bool do_shift = p.flags & 1;
+    const size_t plane = (size_t)Hf * Wf;
+    const float *base = stacks + (((size_t)p.scene * 4 + ss) * V + sn) * 3 * plane;
+    auto lerp = [&](float a, float c) { return __fadd_rn(__fmul_rn(a, t.w0), __fmul_rn(c, t.w1)); };
+    double local = 0.0;
+    for (int x = threadIdx.x; x < ps; x += blockDim.x) {
+        int yy = y, xx = x;
+        unrotate(p.rot, ps, yy, xx);
+        const int Y = p.y0 + yy, X = p.x0 + xx;           // downsampled-frame coordinates
+        float c[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float *pl = base + ch * plane;
+            auto at = [&](int yd, int xd) { return pl[(size_t)(yd * p.f) * Wf + xd * p.f]; };
+            if (!do_shift) { c[ch] = at(Y, X); continue; }
+            const int x0 = roll_src(X, t.s0, Wd), x1 = roll_src(X, t.s1, Wd);
+            if (ss == 0) { c[ch] = lerp(at(Y, x0), at(Y, x1)); continue; }
+            const int sg = ss == 2 ? -1 : 1;              // the I stack's vertical pass rolls by -s (:971-975)
+            const int ya = roll_src(Y, sg * t.s0, Hd), yb = roll_src(Y, sg * t.s1, Hd);
+            if (ss == 1) { c[ch] = lerp(at(ya, X), at(yb, X)); continue; }
+            c[ch] = lerp(lerp(at(ya, x0), at(ya, x1)), lerp(at(yb, x0), at(yb, x1)));
+        }
+        if (p.flags & 2) redist_color(mat + 9 * b, c[0], c[1], c[2]);
+        if (p.flags & 4) { c[0] = __fmul_rn(c[0], p.bright); c[1] = __fmul_rn(c[1], p.bright); c[2] = __fmul_rn(c[2], p.bright); }
+        float *o = out + ((((size_t)so * B + b) * V + n) * 3 * ps + y) * ps + x;
+        o[0] = c[0]; o[(size_t)ps * ps] = c[1]; o[(size_t)2 * ps * ps] = c[2];
+        local += (double)c[0] + (double)c[1] + (double)c[2];
+    }
+    if (so == 0 && mean_sum) {                            // Contrast's mean is over data[0] (:741)
+        __shared__ double red[128];
+        red[threadIdx.x] = local;
+        __syncthreads();
+        for (int k = 64; k > 0; k >>= 1) {
+            if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) atomicAdd(mean_sum + b, red[0]);
+    }
+}
+
+// centre view, ground truth, MPI planes and mask.  grid: (B * (3 + 1 + 5P + 1) planes * ps rows)
+__global__ __launch_bounds__(128) void patch_planes_kernel(
+    const float *__restrict__ center, const float *__restrict__ gt, const float *__restrict__ mpi,
+    const int32_t *__restrict__ mask, const int32_t *__restrict__ ip, const float *__restrict__ fp,
+    const double *__restrict__ mat, float *__restrict__ o_center, float *__restrict__ o_gt,
+    float *__restrict__ o_mpi, int32_t *__restrict__ o_mask, int B, int P, int Hf, int Wf, int ps)
+{
+    const int nplanes = 1 + 1 + 5 * P + 1;                // centre (3 channels at once), gt, mpi, mask
+    int r = blockIdx.x;
+    const int y = r % ps; r /= ps;
+    const int k = r % nplanes;
+    const int b = r / nplanes;
+    const PatchSample p = patch_sample(ip, fp, b);
+    const size_t plane = (size_t)Hf * Wf;
+    for (int x = threadIdx.x; x < ps; x += blockDim.x) {
+        int yy = y, xx = x;
+        if (k != nplanes - 1) unrotate(p.rot, ps, yy, xx);            // the mask is not rotated (:1056)
+        const size_t src = (size_t)((p.y0 + yy) * p.f) * Wf + (p.x0 + xx) * p.f;
+        const size_t dst = (size_t)y * ps + x;
+        if (k == 0) {                                                  // centre: no shift (:929-978 touch stacks only)
+            const float *pc = center + (size_t)p.scene * 3 * plane;
+            float c0 = pc[src], c1 = pc[plane + src], c2 = pc[2 * plane + src];
+            if (p.flags & 2) redist_color(mat + 9 * b, c0, c1, c2);
+            if (p.flags & 4) { c0 = __fmul_rn(c0, p.bright); c1 = __fmul_rn(c1, p.bright); c2 = __fmul_rn(c2, p.bright); }
+            float *o = o_center + (size_t)b * 3 * ps * ps + dst;
+            o[0] = c0; o[(size_t)ps * ps] = c1; o[(size_t)2 * ps * ps] = c2;
+        } else if (k == 1) {                                           // gt / f - disp (:506-507, :982-983)
+            float g = __fdiv_rn(gt[(size_t)p.scene * plane + src], p.fdiv);
+            if (p.flags & 1) g = __fsub_rn(g, p.disp);
+            o_gt[(size_t)b * ps * ps + dst] = g;
+        } else if (k == nplanes - 1) {
+            o_mask[(size_t)b * ps * ps + dst] = mask[(size_t)p.scene * plane + src];
+        } else {                                                       // mpi[:, 4] carries the same corrections
+            const int q = k - 2;
+            float v = mpi[((size_t)p.scene * 5 * P + q) * plane + src];
+            if (q % 5 == 4) {
+                v = __fdiv_rn(v, p.fdiv);
+                if (p.flags & 1) v = __fsub_rn(v, p.disp);
+            }
+            o_mpi[((size_t)b * 5 * P + q) * ps * ps + dst] = v;
+        }
+    }
+}
+
+// Contrast (:740-751): x*alpha + mean*(1-alpha) on the four stacks and the centre view
+__global__ void patch_contrast_kernel(float *__restrict__ stacks, float *__restrict__ center,
+                                      const double *__restrict__ mean_sum, const float *__restrict__ alpha,
+                                      int B, int per_stack /* V*3*ps*ps */, int per_center)
+{
+    const long long n_st = (long long)4 * B * per_stack, total = n_st + (long long)B * per_center;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        float *ptr;
+        int b;
+        if (idx < n_st) { b = (int)((idx / per_stack) % B); ptr = stacks + idx; }
+        else { b = (int)((idx - n_st) / per_center); ptr = center + (idx - n_st); }
+        const float a = alpha[2 * b];                               // float32(alpha), float32(1 - alpha)
+        const float mean = (float)(mean_sum[b] / (double)per_stack);
+        const float off = __fmul_rn(mean, alpha[2 * b + 1]);
+        *ptr = __fadd_rn(__fmul_rn(*ptr, a), off);
+    }
+}
+
 // Ensamble reduce (ensamble.py:78-101)
 __global__ void ensamble_reduce_kernel(const float *__restrict__ means, const float *__restrict__ logvars,
                                        const float *__restrict__ grid, float *__restrict__ mean,
@@ -759,4 +930,36 @@ extern "C" int mmlf_ensamble_reduce(const float *means, const float *logvars, co
     hipLaunchKernelGGL(ensamble_reduce_kernel, dim3(ew_blocks(total, 64)), dim3(64), 0, (hipStream_t)stream, means,
                        logvars, grid, mean, logvar, posterior, S, H * W, total);
     return mmlf_launch_status("mmlf_ensamble_reduce");
+}
+
+extern "C" int mmlf_patch_gather(const float *stacks, const float *center, const float *gt, const float *mpi,
+                                 const int32_t *mask, int S, int V, int P, int Hf, int Wf, const int32_t *iparam,
+                                 const float *fparam, const int32_t *tab_s, const float *tab_w, const double *mat,
+                                 const int32_t *rot_src, float *o_stacks, float *o_center, float *o_gt, float *o_mpi,
+                                 int32_t *o_mask, double *mean_sum, int B, int ps, void *stream)
+{
+    MMLF_CHECK_ARG(stacks && center && gt && mask && iparam && fparam && tab_s && tab_w && mat && rot_src,
+                   "mmlf_patch_gather: null input");
+    MMLF_CHECK_ARG(o_stacks && o_center && o_gt && o_mask, "mmlf_patch_gather: null output");
+    MMLF_CHECK_ARG(S > 0 && V > 0 && P >= 0 && Hf > 0 && Wf > 0 && B > 0 && ps > 0,
+                   "mmlf_patch_gather: bad shape S=%d V=%d P=%d frame %dx%d B=%d ps=%d", S, V, P, Hf, Wf, B, ps);
+    MMLF_CHECK_ARG(P == 0 || (mpi && o_mpi), "mmlf_patch_gather: P=%d but no mpi buffers", P);
+    MMLF_CHECK_ARG((long long)B * 4 * V * ps < (1ll << 31), "mmlf_patch_gather: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(patch_stacks_kernel, dim3((unsigned)(B * 4 * V * ps)), dim3(128), 0, st, stacks, iparam, fparam,
+                       tab_s, tab_w, mat, rot_src, o_stacks, mean_sum, B, V, Hf, Wf, ps);
+    hipLaunchKernelGGL(patch_planes_kernel, dim3((unsigned)(B * (3 + 5 * P) * ps)), dim3(128), 0, st, center, gt, mpi,
+                       mask, iparam, fparam, mat, o_center, o_gt, o_mpi, o_mask, B, P, Hf, Wf, ps);
+    return mmlf_launch_status("mmlf_patch_gather");
+}
+
+extern "C" int mmlf_patch_contrast(float *o_stacks, float *o_center, const double *mean_sum, const float *alpha,
+                                   int B, int V, int ps, void *stream)
+{
+    MMLF_CHECK_ARG(o_stacks && o_center && mean_sum && alpha && B > 0 && V > 0 && ps > 0,
+                   "mmlf_patch_contrast: bad argument");
+    const long long total = (long long)B * (4 * V + 1) * 3 * ps * ps;
+    hipLaunchKernelGGL(patch_contrast_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, o_stacks,
+                       o_center, mean_sum, alpha, B, V * 3 * ps * ps, 3 * ps * ps);
+    return mmlf_launch_status("mmlf_patch_contrast");
 }

@@ -105,3 +105,17 @@ def synth_inputs(batch, ps, views=9, seed=0, ps_w=None):
     gt = (4.0 * rs.uniform(size=(batch, ps, ps_w)) - 2.0).astype(np.float32)
     mask = np.ones((batch, ps, ps_w), dtype=np.int32)
     return stacks, gt, mask
+
+
+def synth_scene(seed, H, W, views=9, planes=2):
+    """One cached scene tuple as reference hci4d.py:150-254 builds it:
+    (h, v, i, d, center, gt, mpi, mask, index) with stacks (views,3,H,W) float32 in [0,1),
+    gt in [-2,2), mpi (planes,5,H,W) float32 (plane 3 = weight, 4 = disparity), mask int64 {0,1}."""
+    rs = np.random.RandomState(5000 + seed)
+    stacks = [rs.uniform(0.0, 1.0, size=(views, 3, H, W)).astype(np.float32) for _ in range(4)]
+    center = stacks[1][int(views / 2)].copy()
+    gt = (4.0 * rs.uniform(size=(H, W)) - 2.0).astype(np.float32)
+    mpi = rs.uniform(0.0, 1.0, size=(planes, 5, H, W)).astype(np.float32)
+    mpi[:, 4] = (4.0 * mpi[:, 4] - 2.0).astype(np.float32)
+    mask = (rs.uniform(size=(H, W)) > 0.2).astype(np.int64)
+    return (*stacks, center, gt, mpi, mask, np.atleast_1d(seed))

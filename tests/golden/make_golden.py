@@ -17,6 +17,8 @@ Groups:
   G2  full-size net (defaults), formula weights: train/eval outputs, loss, sampled grads.
   G4  hci4d.Shift alone and the 70-member Ensamble on a tiny UPR net.
   G5  losses and dl helpers.
+  G6  multimodal losses.
+  G7  the training patch pipeline (hci4d transforms as train/cli.py composes them).
 """
 import os
 import sys
@@ -297,15 +299,60 @@ def g6_multimodal():
     print('G6 ok', {k: np.asarray(v).shape for k, v in rec.items()})
 
 
+def g7_patch_pipeline():
+    """The training transform chain of reference train/cli.py:72-91 on synthetic cached scenes; Python's
+    `random` is seeded per sample, so a test that seeds it the same way draws the same parameters."""
+    import copy
+    import random
+    from mmlf.data import hci4d as ref_hci4d
+    rec = {}
+    cases = [('a', 0, 72, 80, 8, 2, True), ('b', 1, 128, 136, 8, 4, True), ('c', 2, 40, 44, 6, 1, False),
+             ('d', 3, 96, 100, 16, 2, True)]
+    for tag, seed, H, W, ps, max_down, augment in cases:
+        scene = synth.synth_scene(seed, H, W)
+        if augment:
+            chain = [ref_hci4d.RandomDownSampling(max_down), ref_hci4d.RandomShift(1.0),
+                     ref_hci4d.RandomCrop(ps + 2 * 4 * 2), ref_hci4d.CenterCrop(ps), ref_hci4d.RandomRotate(),
+                     ref_hci4d.RedistColor(), ref_hci4d.Brightness(), ref_hci4d.Contrast()]
+        else:
+            chain = [ref_hci4d.RandomCrop(ps + 2 * 4 * 2), ref_hci4d.CenterCrop(ps)]
+        rec[f'{tag}.cfg'] = np.array([seed, H, W, ps, max_down, int(augment)])
+        for k in range(6):
+            random.seed(100 * seed + k)
+            data = copy.deepcopy(scene)            # hci4d.py:289-291
+            for tf in chain:
+                data = tf(data)
+            for name, arr in zip(('h', 'v', 'i', 'd', 'center', 'gt', 'mpi', 'mask'), data):
+                rec[f'{tag}.{k}.{name}'] = np.ascontiguousarray(arr)
+    # a fixed pre-shift (--train_shift) in front of the chain, train/cli.py:93-94
+    scene = synth.synth_scene(4, 64, 72)
+    chain = [ref_hci4d.Shift(0.37), ref_hci4d.RandomDownSampling(2), ref_hci4d.RandomShift(1.0),
+             ref_hci4d.RandomCrop(8 + 16), ref_hci4d.CenterCrop(8), ref_hci4d.RandomRotate(),
+             ref_hci4d.RedistColor(), ref_hci4d.Brightness(), ref_hci4d.Contrast()]
+    for k in range(3):
+        random.seed(900 + k)
+        data = copy.deepcopy(scene)
+        for tf in chain:
+            data = tf(data)
+        for name, arr in zip(('h', 'v', 'i', 'd', 'center', 'gt', 'mpi', 'mask'), data):
+            rec[f'e.{k}.{name}'] = np.ascontiguousarray(arr)
+    np.savez_compressed(os.path.join(HERE, 'g7_patch_pipeline.npz'), **rec)
+    print('G7 ok', len(rec), 'arrays')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'g6':
         g6_multimodal()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g7':
+        g7_patch_pipeline()
         sys.exit(0)
     g1_tiny()
     g4_shift_ensamble()
     g5_losses()
     g2_full()
     g6_multimodal()
+    g7_patch_pipeline()
     sizes = {f: os.path.getsize(os.path.join(HERE, f)) for f in sorted(os.listdir(HERE))
              if f.endswith('.npz')}
     print(sizes)
