@@ -1,12 +1,14 @@
-// conv.hip -- fp32 MFMA implicit-GEMM kernels for the k=2 convolutions of the EPI-stack CNN
+// conv.hip -- MFMA implicit-GEMM kernels for the k=2 convolutions of the EPI-stack CNN
 // (forward, data gradient, weight+bias gradient) on the padded NHWC grid.  gfx950 only.
+// Two arithmetic paths with the same interfaces: exact-f32 MFMA (conv4tap_kernel, wgrad4tap_kernel) and
+// the default split-bf16 path at f32 accuracy (conv4tap_x6s_kernel, wgrad4tap_x6w/x6n_kernel).
 //
 // Arithmetic replaced: nn.Conv2d(k=2, pad 1|0) forward / backward as used by
 // reference mmlf/model/feed_forward.py:123,125 (autograd via mmlf/train/cli.py:257).
 //
 // All three are 4-tap correlations over the flat grid position q with tap offsets
-// {0, 1, P, P+1} (include/mmlf_hip.h).  v_mfma_f32_32x32x2_f32 is an exact f32 fma chain, so
-// results are float32-exact up to summation order.
+// {0, 1, P, P+1} (include/mmlf_hip.h).  v_mfma_f32_32x32x2_f32 is an exact f32 fma chain, so the
+// exact-f32 path is float32-exact up to summation order.
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/mmlf_hip.h"
@@ -1265,10 +1267,8 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
 }
 
 // ------------------------------------------------------------------ split-bf16 ("bf16x6") entry points
-// narrow layers (N <= 96) run the 16x16x32-MFMA variant (measured ~10 % faster there; the 32x32x16
-// variant wins at N = 288).  Packing and launch pick by the same rule, so the layouts always agree.
-// Packed column count NP of the split forward/dgrad kernels: 16-column granularity up to 96, then the
-// 32x32 tilings.  Packing and launch pick by this one rule, so the layouts always agree.
+// Packed column count NP of the split forward/dgrad kernels: 32, 80, then 16-column granularity up to
+// 128, then 288.  Packing and launch pick by this one rule, so the layouts always agree.
 static inline int x6_np(int N)
 {
     if (N <= 0 || N > 288) return -1;
