@@ -390,15 +390,18 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][2], bq[g % 3][0], acc[mb][g], 0, 0, 0);
-                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][0], bq[g % 3][2], acc[mb][g], 0, 0, 0);
-                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][1], bq[g % 3][1], acc[mb][g], 0, 0, 0);
-                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][1], bq[g % 3][0], acc[mb][g], 0, 0, 0);
-                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][0], bq[g % 3][1], acc[mb][g], 0, 0, 0);
-                acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][0], bq[g % 3][0], acc[mb][g], 0, 0, 0);
-            }
+            // six cross terms, small ones first; the two row blocks alternate so that consecutive MFMAs
+            // never wait on each other's accumulator
+#define X6_TERM(pa, pb)                                                                                      \
+    _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
+        acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][pa], bq[g % 3][pb], acc[mb][g], 0, 0, 0)
+            X6_TERM(2, 0);
+            X6_TERM(0, 2);
+            X6_TERM(1, 1);
+            X6_TERM(1, 0);
+            X6_TERM(0, 1);
+            X6_TERM(0, 0);
+#undef X6_TERM
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
@@ -804,15 +807,10 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
             }                                                                                               \
         }                                                                                                   \
     } while (0)
-#define WN_MFMA6(af, gf, c)                                                                                 \
-    do {                                                                                                    \
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], gf[0], c, 0, 0, 0);                              \
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[2], c, 0, 0, 0);                              \
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[1], c, 0, 0, 0);                              \
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], gf[0], c, 0, 0, 0);                              \
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[1], c, 0, 0, 0);                              \
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], gf[0], c, 0, 0, 0);                              \
-    } while (0)
+    // the six cross terms (activation plane, gradient plane), small ones first; independent accumulators
+    // alternate inside each term
+#define WN_PA(term) ((term) == 0 ? 2 : (term) == 1 ? 0 : (term) <= 3 ? 1 : 0)
+#define WN_PB(term) ((term) == 0 ? 0 : (term) == 1 ? 2 : (term) == 2 ? 1 : (term) == 3 ? 0 : (term) == 4 ? 1 : 0)
 
     // transposed-read geometry: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
     const int tq = (lane & 15) >> 2, tp = lane & 3;
@@ -837,7 +835,11 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) af[pl] = tr_frag(a_lane + pl * A_PLANE + 32 * mb, 4 * ROWA);
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) WN_MFMA6(af, gf[nb], acc[mb][nb]);
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[WN_PA(term)], gf[nb][WN_PB(term)],
+                                                                                  acc[mb][nb], 0, 0, 0);
                 }
             } else {
                 bf16x8 af[MB][3];
@@ -851,7 +853,11 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) gf[pl] = tr_frag(g_lane + pl * G_PLANE + 32 * nb, 4 * ROWG);
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) WN_MFMA6(af[mb], gf, acc[mb][nb]);
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][WN_PA(term)], gf[WN_PB(term)],
+                                                                                  acc[mb][nb], 0, 0, 0);
                 }
             }
             __syncthreads();
@@ -859,7 +865,8 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
     }
 #undef WN_GLOAD
 #undef WN_LSTORE
-#undef WN_MFMA6
+#undef WN_PA
+#undef WN_PB
     constexpr int NP = 16 * NB;
     const int CIP = a.nslice * 16 * MB;
     float *pp = a.part + ((size_t)(split * 4 + t) * CIP + ci0) * NP;
@@ -994,15 +1001,17 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
                     if (nb < NA) WW_STORE_A(nb < NA ? nb : 0, nxt);
                     else if (nb - NA < NG) WW_STORE_G(nb - NA < NG ? nb - NA : 0, nxt);
                 }
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][2], gf[0], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][0], gf[2], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][1], gf[1], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][1], gf[0], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][0], gf[1], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][0], gf[0], acc[mb][nb], 0, 0, 0);
-                }
+                // six cross terms, small ones first; the MB row blocks alternate (independent accumulators)
+#define WW_TERM(pa, pb)                                                                                      \
+    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                        \
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][pa], gf[pb], acc[mb][nb], 0, 0, 0)
+                WW_TERM(2, 0);
+                WW_TERM(0, 2);
+                WW_TERM(1, 1);
+                WW_TERM(1, 0);
+                WW_TERM(0, 1);
+                WW_TERM(0, 0);
+#undef WW_TERM
             }
             static_assert(NA + NG <= NBH, "one staging piece per column block");
             if (c + 2 < c_end) WW_GLOAD(c + 2);
