@@ -924,50 +924,44 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
             for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
 
     float4 ra[NA], rg[NG];
+    // staging items are clamped to the last one instead of predicated: surplus threads load and store that
+    // item again (same value), which keeps the loop free of divergent branches
 #define WW_GLOAD(c)                                                                                         \
     do {                                                                                                    \
         const long long Qc = (long long)(c) * WG_KQ;                                                        \
         _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
-            const int idx = tid + 512 * j;                                                                  \
+            const int idx = min(tid + 512 * j, 66 * FA - 1);                                                \
             const int row = idx / FA, f = idx - row * FA;                                                   \
             const int seg = row >= 33, pix = row - 33 * seg;                                                \
-            const int ch = ci0 + 4 * f;                                                                     \
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
-            if (idx < 66 * FA && ch < a.cs_in)                                                              \
-                v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
-            ra[j] = v;                                                                                      \
+            const int ch = min(ci0 + 4 * f, a.cs_in - 4);                                                   \
+            const float4 v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
+            ra[j] = (ci0 + 4 * f < a.cs_in) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                          \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
-            const int idx = tid + 512 * j;                                                                  \
+            const int idx = min(tid + 512 * j, WG_KQ * FG - 1);                                             \
             const int row = idx / FG, f = idx - row * FG;                                                   \
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
-            if (idx < WG_KQ * FG && 4 * f < a.cs_g)                                                         \
-                v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + 4 * f); \
-            rg[j] = v;                                                                                      \
+            const float4 v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + min(4 * f, a.cs_g - 4)); \
+            rg[j] = (4 * f < a.cs_g) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                 \
         }                                                                                                   \
     } while (0)
 #define WW_STORE_A(j, dst)                                                                                  \
     do {                                                                                                    \
-        const int idx = tid + 512 * (j);                                                                    \
-        if (idx < 66 * FA) {                                                                                \
-            const int row = idx / FA, f = idx - row * FA;                                                   \
-            const int seg = row >= 33, pix = row - 33 * seg;                                                \
-            float4 v = ra[j];             /* ones row -> bias gradient */                                   \
-            const int ch = ci0 + 4 * f;                                                                     \
-            if (ch == a.cin) v.x = 1.f;                                                                     \
-            if (ch + 1 == a.cin) v.y = 1.f;                                                                 \
-            if (ch + 2 == a.cin) v.z = 1.f;                                                                 \
-            if (ch + 3 == a.cin) v.w = 1.f;                                                                 \
-            split_store4(v, (dst) + seg * 3 * A_PLANE + pix * ROWA + 8 * f, A_PLANE);                       \
-        }                                                                                                   \
+        const int idx = min(tid + 512 * (j), 66 * FA - 1);                                                  \
+        const int row = idx / FA, f = idx - row * FA;                                                       \
+        const int seg = row >= 33, pix = row - 33 * seg;                                                    \
+        float4 v = ra[j];                 /* ones row -> bias gradient */                                   \
+        const int ch = ci0 + 4 * f;                                                                         \
+        v.x = ch == a.cin ? 1.f : v.x;                                                                      \
+        v.y = ch + 1 == a.cin ? 1.f : v.y;                                                                  \
+        v.z = ch + 2 == a.cin ? 1.f : v.z;                                                                  \
+        v.w = ch + 3 == a.cin ? 1.f : v.w;                                                                  \
+        split_store4(v, (dst) + seg * 3 * A_PLANE + pix * ROWA + 8 * f, A_PLANE);                           \
     } while (0)
 #define WW_STORE_G(j, dst)                                                                                  \
     do {                                                                                                    \
-        const int idx = tid + 512 * (j);                                                                    \
-        if (idx < WG_KQ * FG) {                                                                             \
-            const int row = idx / FG, f = idx - row * FG;                                                   \
-            split_store4(rg[j], (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);                             \
-        }                                                                                                   \
+        const int idx = min(tid + 512 * (j), WG_KQ * FG - 1);                                               \
+        const int row = idx / FG, f = idx - row * FG;                                                       \
+        split_store4(rg[j], (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);                                 \
     } while (0)
 
     const int tq = (lane & 15) >> 2, tp = lane & 3;
@@ -983,41 +977,49 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         if (c_begin + 1 < c_end) WW_GLOAD(c_begin + 1);
         __syncthreads();
         int buf = 0;
-        for (int c = c_begin; c < c_end; ++c) {
-            const char *cur = smem + buf * BUF_BYTES;
-            char *nxt = smem + (buf ^ 1) * BUF_BYTES;
-            const bool stage = c + 1 < c_end;        // registers hold chunk c+1: store it beside the MFMAs
-            bf16x8 af[MB][3];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) af[mb][pl] = tr_frag(cur + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);
-#pragma unroll
-            for (int nb = 0; nb < NBH; ++nb) {
-                bf16x8 gf[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) gf[pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * nb, 4 * ROWG);
-                if (stage) {
-                    if (nb < NA) WW_STORE_A(nb < NA ? nb : 0, nxt);
-                    else if (nb - NA < NG) WW_STORE_G(nb - NA < NG ? nb - NA : 0, nxt);
-                }
-                // six cross terms, small ones first; the MB row blocks alternate (independent accumulators)
-#define WW_TERM(pa, pb)                                                                                      \
+        // One chunk: gradient fragments are read one column block ahead (two register sets); with STAGE the
+        // registers holding chunk c+1 are split and stored into the other buffer, one piece per column
+        // block, branch-free so that the stores interleave with the MFMAs.
+#define WW_TERM(gf, pa, pb)                                                                                  \
     _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                        \
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][pa], gf[pb], acc[mb][nb], 0, 0, 0)
-                WW_TERM(2, 0);
-                WW_TERM(0, 2);
-                WW_TERM(1, 1);
-                WW_TERM(1, 0);
-                WW_TERM(0, 1);
-                WW_TERM(0, 0);
-#undef WW_TERM
-            }
-            static_assert(NA + NG <= NBH, "one staging piece per column block");
+#define WW_CHUNK(STAGE)                                                                                      \
+    do {                                                                                                     \
+        const char *cur = smem + buf * BUF_BYTES;                                                            \
+        char *nxt = smem + (buf ^ 1) * BUF_BYTES;                                                            \
+        bf16x8 af[MB][3], gfr[2][3];                                                                         \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                     \
+            gfr[0][pl] = tr_frag(cur + g_off + pl * G_PLANE, 4 * ROWG);                                      \
+        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                    \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                 \
+                af[mb][pl] = tr_frag(cur + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);                        \
+        _Pragma("unroll") for (int nb = 0; nb < NBH; ++nb) {                                                 \
+            if (nb + 1 < NBH) {                                                                              \
+                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                             \
+                    gfr[(nb + 1) & 1][pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * (nb + 1), 4 * ROWG);   \
+            }                                                                                                \
+            if (STAGE) {                                                                                     \
+                if (nb < NA) WW_STORE_A(nb < NA ? nb : 0, nxt);                                              \
+                else if (nb - NA < NG) WW_STORE_G(nb - NA < NG ? nb - NA : 0, nxt);                          \
+            }                                                                                                \
+            WW_TERM(gfr[nb & 1], 2, 0);                                                                      \
+            WW_TERM(gfr[nb & 1], 0, 2);                                                                      \
+            WW_TERM(gfr[nb & 1], 1, 1);                                                                      \
+            WW_TERM(gfr[nb & 1], 1, 0);                                                                      \
+            WW_TERM(gfr[nb & 1], 0, 1);                                                                      \
+            WW_TERM(gfr[nb & 1], 0, 0);                                                                      \
+        }                                                                                                    \
+    } while (0)
+        static_assert(NA + NG <= NBH, "one staging piece per column block");
+        for (int c = c_begin; c + 1 < c_end; ++c) {
+            WW_CHUNK(true);
             if (c + 2 < c_end) WW_GLOAD(c + 2);
             __syncthreads();
             buf ^= 1;
         }
+        WW_CHUNK(false);                     // last chunk: nothing left to stage
+#undef WW_CHUNK
+#undef WW_TERM
     }
 #undef WW_GLOAD
 #undef WW_STORE_A
