@@ -287,29 +287,42 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     const char *in0 = reinterpret_cast<const char *>(a.in);
     const char *wp_base = reinterpret_cast<const char *>(a.wp);
     const size_t tile_bytes = (size_t)MMLF_TILE * a.cs_in * 4;
-    const int n_a = 2 * a.a_pieces, n_pieces = n_a + N_B;
-    // the wave index as the DMA macros see it: re-made opaque every chunk, so that the per-piece address
-    // terms derived from it are recomputed on the scalar unit instead of hoisted into (spilled) SGPRs
-    int wj = w;
+    // Piece ownership, fixed for the launch: of the chunk's pieces j = 0 .. 2*a_pieces + N_B - 1 (activation
+    // pieces first) wave w issues j = w, w+8, ...: nA activation pieces, then nB weight pieces that are
+    // 8 KiB apart in both the packed filter and LDS.  The first half of them goes out in slot 0.
+    const int n_a = 2 * a.a_pieces;
+    const int nA = (n_a - w + 7) >> 3;
+    const int jb0 = w + 8 * nA - n_a;
+    const int nB = (N_B - jb0 + 7) >> 3;
+    int n_mine = nA + nB;                                   // re-made opaque every chunk (see below)
+    unsigned a_src[3], a_dst[3];                            // activation pieces: byte offset in the tile, LDS byte
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int j = w + 8 * k;
+        const int hf = j >= a.a_pieces, blk = j - hf * a.a_pieces;
+        const int pos = 64 * blk + (blk >= 5 ? a.seg_delta : 0);
+        a_src[k] = ((unsigned)pos * (unsigned)a.cs_in + 4u * hf) * 4u;
+        a_dst[k] = (unsigned)(hf * A_HALF + 64 * blk) * 16u;
+    }
+    const unsigned b_src0 = 1024u * jb0, b_dst0 = (unsigned)(A_F4 + 64 * jb0) * 16u;
 
+    // slot 0 = this wave's pieces k < PER_SLOT, slot 1 = the rest; k is a compile-time index
 #define X6_DMA_PIECE(tl, c, buf, k)                                                                      \
     do {                                                                                                 \
-        const int j_ = wj + 8 * (k);                                                                     \
-        if ((k) < PER_WAVE && j_ < n_pieces) {                                                           \
+        if ((k) < PER_WAVE && (k) < n_mine) {                                                            \
             const char *sb_;                                                                             \
             unsigned vo_, d_;                                                                            \
-            if (j_ < n_a) {                                                                              \
-                const int hf_ = j_ >= a.a_pieces, blk_ = j_ - hf_ * a.a_pieces;                          \
-                const int pos_ = 64 * blk_ + (blk_ >= 5 ? a.seg_delta : 0);                              \
-                sb_ = in0 + (size_t)(tl) * tile_bytes + ((size_t)pos_ * a.cs_in + 4 * hf_ + 8 * (c)) * 4; \
+            if ((k) < nA) {                                                                              \
+                sb_ = in0 + (size_t)(tl) * tile_bytes + 32u * (c) + a_src[(k) < 3 ? (k) : 0];            \
                 vo_ = voff_a;                                                                            \
-                d_ = (unsigned)(hf_ * A_HALF + 64 * blk_);                                               \
+                d_ = a_dst[(k) < 3 ? (k) : 0];                                                           \
             } else {                                                                                     \
-                sb_ = wp_base + ((size_t)(c) * B_F4 + 64 * (j_ - n_a)) * 16;                             \
+                const unsigned kb_ = 8192u * (unsigned)((k) - nA);                                       \
+                sb_ = wp_base + (size_t)(c) * (B_F4 * 16) + b_src0 + kb_;                                \
                 vo_ = voff_b;                                                                            \
-                d_ = (unsigned)(A_F4 + 64 * (j_ - n_a));                                                 \
+                d_ = b_dst0 + kb_;                                                                       \
             }                                                                                            \
-            d_ = lds_base + ((buf) * BUF_F4 + d_) * 16u;                                                 \
+            d_ += lds_base + (buf) * (BUF_F4 * 16);                                                      \
             unsigned keep_;                                                                              \
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                       \
                          "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"                           \
@@ -342,7 +355,9 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     int buf = 0;
 
     while (tile < ntiles) {
-        asm volatile("" : "+s"(wj));
+        // opaque to the optimiser: keeps the per-piece address terms derived from it from being hoisted out
+        // of the persistent loop into (spilled) SGPRs; they are recomputed on the scalar unit instead
+        asm volatile("" : "+s"(n_mine));
         const bool more = ntile < ntiles;
         const float4 *base = lds + buf * BUF_F4;
         // lane (r16, q4): row r16 of a 16-position block, tap q4 -> slot offset (q4&1) + (q4>>1)*seg_slot
