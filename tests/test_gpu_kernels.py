@@ -271,3 +271,50 @@ def test_error_convention():
     with pytest.raises(RuntimeError, match='cs_in'):
         call('mmlf_conv2x2', x.data_ptr(), 30, 27, x.data_ptr(), None, 70, x.data_ptr(), 72, 72, 0, 1, 1, 1, 4, 4, 0,
              None, 0, None)
+
+
+@pytest.mark.parametrize('cin,cout,pad', [(280, 280, 1), (280, 280, 0), (70, 70, 1), (27, 70, 1)])
+def test_full_size_adjoint_identities(cin, cout, pad):
+    """BASELINE.json's full size (bs=512, ps=96), where the oracle is too slow: the three conv kernels must be
+    each other's adjoints, <conv(x; W), g> = <x, dgrad(g; W)> = <W, wgrad(x, g)> (+ bias term), which does
+    not depend on the size.  Inputs live directly on the padded grid (device-side random, zero borders)."""
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    dev = _dev()
+    B, H, W = 512, 96, 96
+    geo = engine.Geometry(B, H, W)
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    gen = torch.Generator(device=dev).manual_seed(cin + cout + pad)
+    ih, iw, ioff = (H, W, 1) if pad == 1 else (H + 1, W + 1, 0)
+    oh, ow, ooff = (H + 1, W + 1, 0) if pad == 1 else (H, W, 1)
+
+    def grid_tensor(C, cs, h, w, off):
+        t = torch.zeros(geo.alloc * cs, device=dev)
+        v = t[:geo.NQ * cs].view(B, geo.R, geo.P, cs)
+        v[:, off:off + h, off:off + w, :C] = torch.rand((B, h, w, C), device=dev, generator=gen) - 0.5
+        return t
+
+    x = grid_tensor(cin, cs_in, ih, iw, ioff)
+    g = grid_tensor(cout, cs_out, oh, ow, ooff)
+    w = (torch.rand((cout, cin, 2, 2), device=dev, generator=gen) - 0.5) * 0.1
+    bias = torch.rand(cout, device=dev, generator=gen) - 0.5
+    fwd_shift = 0 if pad == 1 else geo.P + 1
+    out = torch.zeros(geo.alloc * cs_out, device=dev)
+    engine.conv(geo, x, cs_in, cin, engine.pack_filter(w, 0, False), bias, cout, out, cs_out, fwd_shift, oh, ow, False)
+    dx = torch.zeros(geo.alloc * cs_in, device=dev)
+    engine.conv(geo, g, cs_out, cout, engine.pack_filter(w, 0, True), None, cin, dx, cs_in, geo.P + 1 - fwd_shift,
+                ih, iw, False)
+    gw = torch.zeros_like(w)
+    gb = torch.zeros(cout, device=dev)
+    ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout)), device=dev)
+    call('mmlf_conv2x2_wgrad_split' if engine.CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad', ptr(x), cs_in, cin,
+         ptr(g), cs_out, cout, fwd_shift, ptr(gw), ptr(gb), 0, 0, ptr(ws), B, H, W, _lib.stream_ptr())
+    lhs = torch.dot(out.double(), g.double())
+    via_x = torch.dot(x.double(), dx.double()) + torch.dot(bias.double(), gb.double())
+    via_w = torch.dot(w.double().reshape(-1), gw.double().reshape(-1)) + torch.dot(bias.double(), gb.double())
+    scale = float(out.double().abs().mul(g.double().abs()).sum())       # sum |out*g|: the rounding-noise scale
+    assert abs(float(lhs - via_x)) <= 1e-6 * scale, (float(lhs), float(via_x), scale)
+    assert abs(float(lhs - via_w)) <= 1e-6 * scale, (float(lhs), float(via_w), scale)
+    # the bias gradient is the plain column sum of g
+    ref_gb = g[:geo.NQ * cs_out].view(-1, cs_out)[:, :cout].double().sum(0)
+    assert torch.allclose(gb.double(), ref_gb, rtol=1e-5, atol=1e-5 * float(ref_gb.abs().max()))
