@@ -167,6 +167,12 @@ int mmlf_shift_views(const float *h, const float *v, const float *i, const float
 int mmlf_ensamble_reduce(const float *means, const float *logvars, const float *grid, float *mean,
                          float *logvar, float *posterior, int S, int B, int H, int W, void *stream);
 
+/* Discretised Laplace mixture of the ensemble members (mmlf/validate/cli.py:74-118, called at :302,318):
+ * out[b][k][p] (float64) = (1/S) sum_s cdf(edges[k+1]) - cdf(edges[k]) of Laplace(means[s][b][p],
+ * exp(logvars[s][b][p])); edges = n_bins+1 float64 bin edges.  S = 1 is laplace_to_discrete (:90-103). */
+int mmlf_lmm_to_discrete(const float *means, const float *logvars, const double *edges, double *out,
+                         int S, int B, int n_bins, long long HW, void *stream);
+
 /* Training patch pipeline: the transform chain the reference's training CLI
  * composes (mmlf/train/cli.py:72-91) -- RandomDownSampling, RandomShift, RandomCrop + CenterCrop,
  * RandomRotate, RedistColor, Brightness (mmlf/data/hci4d.py:483-510, 907-990, 532-575, 1041-1071,

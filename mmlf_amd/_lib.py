@@ -42,6 +42,7 @@ SIGNATURES = {
     'mmlf_loss_fwd_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     'mmlf_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i64, _d, _vp]),
     'mmlf_shift_views': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_lmm_to_discrete': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     'mmlf_patch_gather': (_i, [_vp] * 5 + [_i] * 5 + [_vp] * 12 + [_i, _i, _vp]),
     'mmlf_patch_contrast': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mmlf_ensamble_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

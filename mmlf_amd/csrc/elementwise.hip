@@ -741,6 +741,38 @@ __global__ void ensamble_reduce_kernel(const float *__restrict__ means, const fl
     }
 }
 
+// Discretised Laplace mixture (validate/cli.py:74-118): out[b][k][p] = mean over members s of
+// cdf(edge[k+1]; m, v) - cdf(edge[k]; m, v) with m = means[s][b][p], v = exp(logvars[s][b][p]) (float32 exp,
+// then float64 like numpy's promotion), accumulated member by member in float64.
+__device__ __forceinline__ double cdf_laplace_f64(double x, double m, double v)
+{
+    const double z = (x - m) / v;
+    return x < m ? exp(z) / 2.0 : 1.0 - exp(-z) / 2.0;
+}
+
+__global__ void lmm_to_discrete_kernel(const float *__restrict__ means, const float *__restrict__ logvars,
+                                       const double *__restrict__ edges, double *__restrict__ out, int S, int B,
+                                       int n_bins, long long HW)
+{
+    const long long total = (long long)B * n_bins * HW;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long p = idx % HW;
+        const long long r = idx / HW;
+        const int k = (int)(r % n_bins);
+        const long long b = r / n_bins;
+        const double e0 = edges[k], e1 = edges[k + 1];
+        double acc = 0.0;
+        for (int s = 0; s < S; ++s) {
+            const size_t o = ((size_t)s * B + b) * HW + p;
+            const double m = (double)means[o];
+            const double v = (double)expf(logvars[o]);
+            acc += cdf_laplace_f64(e1, m, v) - cdf_laplace_f64(e0, m, v);
+        }
+        out[idx] = acc / (double)S;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI wrappers
 // ---------------------------------------------------------------------------------------------
@@ -962,4 +994,15 @@ extern "C" int mmlf_patch_contrast(float *o_stacks, float *o_center, const doubl
     hipLaunchKernelGGL(patch_contrast_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, o_stacks,
                        o_center, mean_sum, alpha, B, V * 3 * ps * ps, 3 * ps * ps);
     return mmlf_launch_status("mmlf_patch_contrast");
+}
+
+extern "C" int mmlf_lmm_to_discrete(const float *means, const float *logvars, const double *edges, double *out,
+                                    int S, int B, int n_bins, long long HW, void *stream)
+{
+    MMLF_CHECK_ARG(means && logvars && edges && out && S > 0 && B > 0 && n_bins > 0 && HW > 0,
+                   "mmlf_lmm_to_discrete: bad argument");
+    const long long total = (long long)B * n_bins * HW;
+    hipLaunchKernelGGL(lmm_to_discrete_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, means,
+                       logvars, edges, out, S, B, n_bins, HW);
+    return mmlf_launch_status("mmlf_lmm_to_discrete");
 }
