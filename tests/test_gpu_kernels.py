@@ -318,3 +318,42 @@ def test_full_size_adjoint_identities(cin, cout, pad):
     # the bias gradient is the plain column sum of g
     ref_gb = g[:geo.NQ * cs_out].view(-1, cs_out)[:, :cout].double().sum(0)
     assert torch.allclose(gb.double(), ref_gb, rtol=1e-5, atol=1e-5 * float(ref_gb.abs().max()))
+
+
+def test_split_arithmetic_is_at_f32_accuracy():
+    """The default split-precision kernels must not be a precision downgrade: against a float64 evaluation
+    of the same convolution (K = 4 x 280 products per output, the dominant layer) their error is no larger
+    than that of the exact-f32 MFMA kernels."""
+    from mmlf_amd import engine
+    dev = _dev()
+    rs = np.random.RandomState(11)
+    B, H, W, cin, cout = 2, 24, 24, 280, 280
+    geo = engine.Geometry(B, H, W)
+    cs = engine.cs_of(cin)
+    x = rs.uniform(-1, 1, (B, cin, H, W)).astype(np.float32)
+    w = rs.uniform(-0.06, 0.06, (cout, cin, 2, 2)).astype(np.float32)
+    xp = np.zeros((B, cin, H + 2, W + 2), np.float64)
+    xp[:, :, 1:-1, 1:-1] = x
+    ref = np.zeros((B, cout, H + 1, W + 1), np.float64)
+    mag = np.zeros_like(ref)                                    # sum |a*b|: the scale rounding errors live on
+    for dy in range(2):
+        for dx in range(2):
+            patch = xp[:, :, dy:dy + H + 1, dx:dx + W + 1]
+            ref += np.einsum('bchw,oc->bohw', patch, w[:, :, dy, dx].astype(np.float64))
+            mag += np.einsum('bchw,oc->bohw', np.abs(patch), np.abs(w[:, :, dy, dx]).astype(np.float64))
+    xg = torch.from_numpy(grid_from_nchw(x, cs, geo, offset=1)).to(dev)
+    err = {}
+    for mode in ('f32', 'bf16x6'):
+        engine.CONV_MODE, keep = mode, engine.CONV_MODE
+        try:
+            pk = engine.pack_filter(torch.from_numpy(w).to(dev), 0, False)
+            out = torch.zeros(geo.alloc * cs, device=dev)
+            engine.conv(geo, xg, cs, cin, pk, None, cout, out, cs, 0, H + 1, W + 1, False)
+        finally:
+            engine.CONV_MODE = keep
+        got, _ = nchw_from_grid(out.cpu().numpy(), cs, cout, geo, H + 1, W + 1, 0)
+        rel = np.abs(got.astype(np.float64) - ref) / mag
+        err[mode] = (rel.mean(), rel.max())
+    assert err['bf16x6'][0] <= 1.1 * err['f32'][0], err       # mean error relative to sum|a*b|
+    assert err['bf16x6'][1] <= 1.5 * err['f32'][1], err       # worst element
+    assert err['f32'][0] < 5e-8 and err['bf16x6'][0] < 5e-8, err
