@@ -79,6 +79,21 @@ int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void *packed, co
                        float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
                        int B, int H, int W, int relu, const float *relu_ref, int cs_ref, void *stream);
 
+/* 2-way f16 split variant ("f16x3"): every operand tensor is scaled by a power of two that brings its max |x|
+ * into [2^14, 2^15), split exactly into two f16 (hi + lo, 22 mantissa bits) and each product evaluated as
+ * hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with f32 accumulation; the scaling is undone exactly in
+ * the epilogue.  Measured error vs a double reference: at the level of the exact-f32 MFMA chain
+ * (tools/f16x2_accuracy.hip), at half the MFMA passes of the bf16 split.  in_amax: device scalar holding
+ * max |in| (any upper bound within 2x is as good); out_amax (nullable): device scalar that receives
+ * max(*out_amax, max |out|) by atomic max -- zero it before the first producer of a tensor.
+ * `packed` holds mmlf_packed_filter_h2_bytes(K, N) bytes (the weights' own scale is stored behind them). */
+int64_t mmlf_packed_filter_h2_bytes(int K, int N);
+int mmlf_pack_filter_h2(const float *w_oihw, void *packed, int Cout, int Cin, int variant, int dgrad, void *stream);
+int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
+                    float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
+                    int B, int H, int W, int relu, const float *relu_ref, int cs_ref,
+                    const float *in_amax, float *out_amax, void *stream);
+
 /* Weight + bias gradient of the convolution above (autograd of feed_forward.py:123,125 reached
  * from train/cli.py:257):  gw[co][ci][tap] (+)= sum_q in[q + off_t][ci] * g[q + g_shift][co],
  * gb[co] (+)= sum_q g[q + g_shift][co].  g must be zero outside its stored extent.

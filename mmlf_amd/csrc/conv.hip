@@ -52,6 +52,9 @@ struct ConvArgs {
     long long NQ;
     int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
     int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6s_kernel)
+    const float *in_amax;                // f16 split: max |in| (device scalar) -> power-of-two operand scale
+    const float *w_scale;                // f16 split: the scale the packed weights carry (device scalar)
+    float *out_amax;                     // optional: running max |out| (device scalar, atomic max)
 };
 
 // epilogue shared by the f32 and the split-bf16 kernels: D[row = position][col = channel]; a lane
@@ -156,6 +159,71 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsig
     l = cvt_pk_bf16(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xFFFF0000u));
 }
 
+// ---- 2-way f16 split ("f16x3"): x*s = hi + lo with 22 mantissa bits, s a power of two that brings the
+// tensor's max |x| into [2^14, 2^15) (f16 tops out at 65504; the lo halves of all elements within 2^-17 of
+// the maximum stay normal numbers).  Three passes hi*hi + hi*lo + lo*hi on the f16 matrix cores reach the
+// error of the exact-f32 MFMA chain (tools/f16x2_accuracy.hip); scaling by a power of two is exact.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__host__ __device__ __forceinline__ float pow2_scale_for(float amax)
+{
+    unsigned u;
+    __builtin_memcpy(&u, &amax, 4);
+    const int be = (int)((u >> 23) & 0xFF);
+    if (be == 0) return 1.f;                       // all-zero (or denormal) tensor
+    int e = 268 - be;                              // 2^(14 - floor(log2 amax))
+    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    u = (unsigned)e << 23;
+    float r;
+    __builtin_memcpy(&r, &u, 4);
+    return r;
+}
+__device__ __forceinline__ void split2_pair_f16(float a, float b, float s, unsigned &h, unsigned &l)
+{
+    const f32x2_t v = {a * s, b * s};
+    const f16x2_t hh = __builtin_convertvector(v, f16x2_t);
+    const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
+    const f32x2_t r = {v[0] - back[0], v[1] - back[1]};
+    const f16x2_t ll = __builtin_convertvector(r, f16x2_t);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+// max |x| of a float array into *out (non-negative floats order like their bit patterns)
+__global__ void amax_kernel(const float *__restrict__ x, long long n, float *__restrict__ out)
+{
+    float m = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(out), __float_as_uint(m));
+}
+// f16-split filter packing: [chunk][plane(2)][tap(4)][NP][8 f16] of w * scale; *scale_out = scale
+__global__ void pack_filter_h2_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Cout,
+                                      int Cin, int variant, int dgrad, int nchunk, int NP,
+                                      const float *__restrict__ w_amax, float *__restrict__ scale_out)
+{
+    const float sc = pow2_scale_for(*w_amax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = sc;
+    const long long total = (long long)nchunk * 4 * NP * 8;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int j = idx & 7;
+        long long r = idx >> 3;
+        const int n = r % NP; r /= NP;
+        const int t = r & 3; r >>= 2;
+        const int c = (int)r;
+        const int k = 8 * c + j;
+        int ci, co, tsrc;
+        if (!dgrad) { ci = k; co = n; tsrc = t; }
+        else { co = k; ci = n; tsrc = 3 - t; }
+        float v = 0.f;
+        if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 4 + master_tap(tsrc, variant)] * sc;
+        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+        out[((((size_t)c * 2 + 0) * 4 + t) * NP + n) * 8 + j] = __builtin_bit_cast(unsigned short, h);
+        out[((((size_t)c * 2 + 1) * 4 + t) * NP + n) * 8 + j] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
 // split-precision filter packing: [chunk][plane(3)][tap(4)][NP][8 bf16], k = 8*chunk+j
 __global__ void pack_filter_split_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Cout,
                                          int Cin, int variant, int dgrad, int nchunk, int NP)
@@ -198,7 +266,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 16x16 tiling: lane (r16, q4) holds column r16 of each 16-column block and rows 16*mb + 4*q4 + r.
 template <int G>
 __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (&acc)[2][G], long long Q0, int w,
-                                                int r16, int q4)
+                                                int r16, int q4, float unscale_a, float unscale_w, float &run_max)
 {
     const unsigned m = wave_row_mask(a, Q0, w, r16 + 16 * q4) >> (4 * q4);
     const long long qb = Q0 + 32 * w + a.out_shift;                                     // wave-uniform
@@ -229,9 +297,11 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int rc = 16 * (k >> 2) + (k & 3);
-            float v = acc[k >> 2][nb][k & 3] + bvn;
+            float v = acc[k >> 2][nb][k & 3] * unscale_a * unscale_w + bvn;   // exact: powers of two (1 on the bf16 path)
             if (a.relu) v = fmaxf(v, 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((keep >> rc & 1) ? v : 0.f), ob,
+            v = (keep >> rc & 1) ? v : 0.f;
+            run_max = fmaxf(run_max, fabsf(v));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ob,
                                                   lo + (unsigned)rc * a.cs_out * 4u + 64 * nb, 0, 0);
         }
     }
@@ -249,7 +319,9 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
 // per wave per chunk the DMA latency of a single double-buffered workgroup is exposed.
 // G = number of 16-column output blocks (NP = 16*G packed columns): 2, 5 (the 70-channel layers: 80
 // columns instead of 96), 6, 7, 8 or 18.
-template <int G>
+// PL = operand planes: 3 = bf16 3-way split, six passes ("bf16x6"); 2 = f16 2-way split of the scaled
+// operands, three passes ("f16x3").
+template <int G, int PL>
 __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
 {
     constexpr int NP = G * 16;
@@ -259,7 +331,7 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     // instead of 2 x 257.  Otherwise two 320-slot segments (rows y and y+1) are loaded.
     constexpr int A_HALF = 640;
     constexpr int A_F4 = 2 * A_HALF;
-    constexpr int B_F4 = 12 * NP;
+    constexpr int B_F4 = 4 * PL * NP;
     constexpr int BUF_F4 = A_F4 + B_F4;
     constexpr int N_B = B_F4 / 64;
     constexpr int PER_WAVE = (20 + N_B + 7) / 8;      // upper bound (two-segment mode: 20 A pieces)
@@ -322,7 +394,7 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
                 vo_ = voff_b;                                                                            \
                 d_ = b_dst0 + kb_;                                                                       \
             }                                                                                            \
-            d_ += lds_base + (buf) * (BUF_F4 * 16);                                                      \
+            d_ = __builtin_amdgcn_readfirstlane(d_ + lds_base + (buf) * (BUF_F4 * 16));                  \
             unsigned keep_;                                                                              \
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                       \
                          "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"                           \
@@ -347,6 +419,13 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     int tile = first_tile, c = 0;          // chunk being multiplied
     int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
     if (tile >= ntiles) return;
+    // f16 split: operand scales (powers of two) and what undoes them in the epilogue
+    float scale_a = 1.f, unscale_a = 1.f, unscale_w = 1.f, run_max = 0.f;
+    if constexpr (PL == 2) {
+        scale_a = pow2_scale_for(*a.in_amax);
+        unscale_a = 1.f / scale_a;
+        unscale_w = 1.f / *a.w_scale;
+    }
     X6_DMA_SLOT(ntile, nc, 0, 0);
     X6_DMA_SLOT(ntile, nc, 0, 1);
     if (++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
@@ -369,30 +448,37 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) ra[mb][hf] = ap[16 * mb + hf * A_HALF];
-        bf16x8 bq[3][3];                                       // rotating [slot][plane] weight fragments
+        bf16x8 bq[3][PL];                                      // rotating [slot][plane] weight fragments
 #pragma unroll
         for (int g0 = 0; g0 < 2; ++g0)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bq[g0][pl] = bp[pl * 4 * NP + 16 * g0];
-        bf16x8 asp[2][3];                                      // [row block][plane] split activations
+            for (int pl = 0; pl < PL; ++pl) bq[g0][pl] = bp[pl * 4 * NP + 16 * g0];
+        bf16x8 asp[2][PL];                                     // [row block][plane] split activations
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             unsigned hh[4], mm[4], ll[4];
-            split3_pair(ra[mb][0].x, ra[mb][0].y, hh[0], mm[0], ll[0]);
-            split3_pair(ra[mb][0].z, ra[mb][0].w, hh[1], mm[1], ll[1]);
-            split3_pair(ra[mb][1].x, ra[mb][1].y, hh[2], mm[2], ll[2]);
-            split3_pair(ra[mb][1].z, ra[mb][1].w, hh[3], mm[3], ll[3]);
-            const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vm = {mm[0], mm[1], mm[2], mm[3]},
-                          vl = {ll[0], ll[1], ll[2], ll[3]};
+            if constexpr (PL == 3) {
+                split3_pair(ra[mb][0].x, ra[mb][0].y, hh[0], mm[0], ll[0]);
+                split3_pair(ra[mb][0].z, ra[mb][0].w, hh[1], mm[1], ll[1]);
+                split3_pair(ra[mb][1].x, ra[mb][1].y, hh[2], mm[2], ll[2]);
+                split3_pair(ra[mb][1].z, ra[mb][1].w, hh[3], mm[3], ll[3]);
+                const u32x4_t vm = {mm[0], mm[1], mm[2], mm[3]};
+                asp[mb][1] = __builtin_bit_cast(bf16x8, vm);
+            } else {
+                split2_pair_f16(ra[mb][0].x, ra[mb][0].y, scale_a, hh[0], ll[0]);
+                split2_pair_f16(ra[mb][0].z, ra[mb][0].w, scale_a, hh[1], ll[1]);
+                split2_pair_f16(ra[mb][1].x, ra[mb][1].y, scale_a, hh[2], ll[2]);
+                split2_pair_f16(ra[mb][1].z, ra[mb][1].w, scale_a, hh[3], ll[3]);
+            }
+            const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {ll[0], ll[1], ll[2], ll[3]};
             asp[mb][0] = __builtin_bit_cast(bf16x8, vh);
-            asp[mb][1] = __builtin_bit_cast(bf16x8, vm);
-            asp[mb][2] = __builtin_bit_cast(bf16x8, vl);
+            asp[mb][PL - 1] = __builtin_bit_cast(bf16x8, vl);
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (g + 2 < G) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bq[(g + 2) % 3][pl] = bp[pl * 4 * NP + 16 * (g + 2)];
+                for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bp[pl * 4 * NP + 16 * (g + 2)];
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
@@ -405,18 +491,29 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // six cross terms, small ones first; the two row blocks alternate so that consecutive MFMAs
-            // never wait on each other's accumulator
+            // cross terms, small ones first; the two row blocks alternate so that consecutive MFMAs never
+            // wait on each other's accumulator
 #define X6_TERM(pa, pb)                                                                                      \
     _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
         acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][pa], bq[g % 3][pb], acc[mb][g], 0, 0, 0)
-            X6_TERM(2, 0);
-            X6_TERM(0, 2);
-            X6_TERM(1, 1);
-            X6_TERM(1, 0);
-            X6_TERM(0, 1);
-            X6_TERM(0, 0);
+#define H2_TERM(pa, pb)                                                                                      \
+    _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
+        acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),          \
+                                                            __builtin_bit_cast(f16x8, bq[g % 3][pb]), acc[mb][g], 0, 0, 0)
+            if constexpr (PL == 3) {
+                X6_TERM(2, 0);
+                X6_TERM(0, 2);
+                X6_TERM(1, 1);
+                X6_TERM(1, 0);
+                X6_TERM(0, 1);
+                X6_TERM(0, 0);
+            } else {
+                H2_TERM(1, 0);
+                H2_TERM(0, 1);
+                H2_TERM(0, 0);
+            }
 #undef X6_TERM
+#undef H2_TERM
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
@@ -424,7 +521,7 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
         // BEFORE the epilogue, so that its stores (same counter) stay in flight across the barrier
         X6_DMA_WAIT();
         if (++c == a.nchunk) {
-            conv_epilogue16<G>(a, acc, (long long)tile * MMLF_TILE, w, r16, q4);
+            conv_epilogue16<G>(a, acc, (long long)tile * MMLF_TILE, w, r16, q4, unscale_a, unscale_w, run_max);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -436,6 +533,10 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
         }
         __syncthreads();
         buf ^= 1;
+    }
+    if (a.out_amax) {                      // one atomic per wave per launch
+        for (int o = 32; o > 0; o >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, o));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.out_amax), __float_as_uint(run_max));
     }
 #undef X6_DMA_PIECE
 #undef X6_DMA_SLOT
@@ -1353,42 +1454,62 @@ static int device_cus()
 }
 
 // persistent launches: one workgroup per CU (two for the narrow variants), each walks tiles b, b+grid, ...
-template <int G>
+template <int G, int PL>
 static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (2 * 640 + 12 * G * 16) * sizeof(float4);
+    constexpr size_t lds = 2 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     long long grid = (G <= 6 ? 2ll : 1ll) * device_cus();
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(conv4tap_x6s_kernel<G>, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
-    return mmlf_launch_status("mmlf_conv2x2_split");
+    hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL>), dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
+    return mmlf_launch_status(PL == 3 ? "mmlf_conv2x2_split" : "mmlf_conv2x2_h2");
 }
 
-extern "C" int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
-                                  float *out, int cs_out, int N_store, int out_shift, int vh, int vw, int B, int H,
-                                  int W, int relu, const float *relu_ref, int cs_ref, void *stream)
+template <int PL>
+static int launch_conv_split(int np, const ConvArgs &a, long long ntiles, hipStream_t st)
 {
-    MMLF_CHECK_ARG(in && packed && out, "mmlf_conv2x2_split: null pointer");
-    MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0, "mmlf_conv2x2_split: bad shape B=%d H=%d W=%d", B, H, W);
-    MMLF_CHECK_ARG(cs_in > 0 && cs_in % 8 == 0, "mmlf_conv2x2_split: cs_in=%d must be a multiple of 8", cs_in);
-    MMLF_CHECK_ARG(K > 0 && (K + 7) / 8 * 8 == cs_in, "mmlf_conv2x2_split: K=%d does not match cs_in=%d", K, cs_in);
+    switch (np) {
+    case 32: return launch_conv_x6s<2, PL>(a, ntiles, st);
+    case 80: return launch_conv_x6s<5, PL>(a, ntiles, st);
+    case 96: return launch_conv_x6s<6, PL>(a, ntiles, st);
+    case 112: return launch_conv_x6s<7, PL>(a, ntiles, st);
+    case 128: return launch_conv_x6s<8, PL>(a, ntiles, st);
+    default: return launch_conv_x6s<18, PL>(a, ntiles, st);
+    }
+}
+
+static int conv_split_impl(const char *who, int planes, const float *in, int cs_in, int K, const void *packed,
+                           const float *bias, int N, float *out, int cs_out, int N_store, int out_shift, int vh,
+                           int vw, int B, int H, int W, int relu, const float *relu_ref, int cs_ref,
+                           const float *in_amax, float *out_amax, void *stream)
+{
+    MMLF_CHECK_ARG(in && packed && out, "%s: null pointer", who);
+    MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0, "%s: bad shape B=%d H=%d W=%d", who, B, H, W);
+    MMLF_CHECK_ARG(cs_in > 0 && cs_in % 8 == 0, "%s: cs_in=%d must be a multiple of 8", who, cs_in);
+    MMLF_CHECK_ARG(K > 0 && (K + 7) / 8 * 8 == cs_in, "%s: K=%d does not match cs_in=%d", who, K, cs_in);
     const int np = x6_np(N);
-    MMLF_CHECK_ARG(np > 0, "mmlf_conv2x2_split: N=%d not supported (max 288)", N);
-    MMLF_CHECK_ARG(N_store > 0 && N_store <= cs_out && N_store <= np,
-                   "mmlf_conv2x2_split: N_store=%d vs cs_out=%d NP=%d", N_store, cs_out, np);
+    MMLF_CHECK_ARG(np > 0, "%s: N=%d not supported (max 288)", who, N);
+    MMLF_CHECK_ARG(N_store > 0 && N_store <= cs_out && N_store <= np, "%s: N_store=%d vs cs_out=%d NP=%d", who,
+                   N_store, cs_out, np);
     Grid g = make_grid(B, H, W);
-    MMLF_CHECK_ARG(out_shift >= 0 && out_shift <= g.P + 1, "mmlf_conv2x2_split: out_shift=%d", out_shift);
-    MMLF_CHECK_ARG(!relu_ref || cs_ref >= N_store, "mmlf_conv2x2_split: cs_ref=%d < N_store", cs_ref);
-    MMLF_CHECK_ARG((long long)cs_in * 4 * 64 < (1ll << 31), "mmlf_conv2x2_split: cs_in too large");
+    MMLF_CHECK_ARG(out_shift >= 0 && out_shift <= g.P + 1, "%s: out_shift=%d", who, out_shift);
+    MMLF_CHECK_ARG(!relu_ref || cs_ref >= N_store, "%s: cs_ref=%d < N_store", who, cs_ref);
+    MMLF_CHECK_ARG((long long)cs_in * 4 * 64 < (1ll << 31), "%s: cs_in too large", who);
+    MMLF_CHECK_ARG(planes == 3 || in_amax, "%s: the f16 split needs the input's max |x|", who);
     ConvArgs a;
     a.in = in; a.wp = reinterpret_cast<const float *>(packed); a.bias = bias; a.out = out; a.ref = relu_ref;
     a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
     a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
+    a.in_amax = in_amax; a.out_amax = out_amax;
+    // the f16-packed filter ends with the scale it carries
+    a.w_scale = planes == 2 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed) +
+                                                                (size_t)(cs_in / 8) * 8 * np * 16)
+                            : nullptr;
     if (g.P + 257 <= 640) {   // one contiguous window of 257 + P positions
         a.a_pieces = (g.P + 257 + 63) / 64; a.seg_slot = g.P; a.seg_delta = 0;
     } else {                  // two 320-slot segments: rows y and y+1
@@ -1396,12 +1517,54 @@ extern "C" int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void 
     }
     const long long ntiles = g.NQpad / MMLF_TILE;
     hipStream_t st = (hipStream_t)stream;
-    switch (np) {
-    case 32: return launch_conv_x6s<2>(a, ntiles, st);
-    case 80: return launch_conv_x6s<5>(a, ntiles, st);
-    case 96: return launch_conv_x6s<6>(a, ntiles, st);
-    case 112: return launch_conv_x6s<7>(a, ntiles, st);
-    case 128: return launch_conv_x6s<8>(a, ntiles, st);
-    default: return launch_conv_x6s<18>(a, ntiles, st);
-    }
+    return planes == 3 ? launch_conv_split<3>(np, a, ntiles, st) : launch_conv_split<2>(np, a, ntiles, st);
+}
+
+extern "C" int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
+                                  float *out, int cs_out, int N_store, int out_shift, int vh, int vw, int B, int H,
+                                  int W, int relu, const float *relu_ref, int cs_ref, void *stream)
+{
+    return conv_split_impl("mmlf_conv2x2_split", 3, in, cs_in, K, packed, bias, N, out, cs_out, N_store, out_shift,
+                           vh, vw, B, H, W, relu, relu_ref, cs_ref, nullptr, nullptr, stream);
+}
+
+// ------------------------------------------------------------------ f16 2-way split ("f16x3") entry points
+extern "C" int64_t mmlf_packed_filter_h2_bytes(int K, int N)
+{
+    const int np = x6_np(N);
+    if (np < 0 || K <= 0) return -1;
+    return (int64_t)((K + 7) / 8) * 8 * np * 16 + 16;      // + the scale the packed weights carry
+}
+
+extern "C" int mmlf_pack_filter_h2(const float *w, void *packed, int Cout, int Cin, int variant, int dgrad,
+                                   void *stream)
+{
+    MMLF_CHECK_ARG(w && packed, "mmlf_pack_filter_h2: null pointer");
+    MMLF_CHECK_ARG(variant >= 0 && variant <= 2, "mmlf_pack_filter_h2: bad variant %d", variant);
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const int NP = x6_np(N);
+    MMLF_CHECK_ARG(NP > 0, "mmlf_pack_filter_h2: N=%d not supported (max 288)", N);
+    const int nchunk = (K + 7) / 8;
+    hipStream_t st = (hipStream_t)stream;
+    float *tail = reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + (size_t)nchunk * 8 * NP * 16);
+    // tail[0] = scale, tail[1] = max |w| (scratch)
+    if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return mmlf_fail("mmlf_pack_filter_h2: memset failed");
+    const long long nw = (long long)Cout * Cin * 4;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((nw + 1023) / 1024 > 256 ? 256 : (nw + 1023) / 1024)), dim3(256),
+                       0, st, w, nw, tail + 1);
+    const long long total = (long long)nchunk * 32 * NP;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_filter_h2_kernel, dim3(blocks), dim3(256), 0, st, w, (unsigned short *)packed, Cout, Cin,
+                       variant, dgrad, nchunk, NP, tail + 1, tail);
+    return mmlf_launch_status("mmlf_pack_filter_h2");
+}
+
+extern "C" int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
+                               float *out, int cs_out, int N_store, int out_shift, int vh, int vw, int B, int H,
+                               int W, int relu, const float *relu_ref, int cs_ref, const float *in_amax,
+                               float *out_amax, void *stream)
+{
+    return conv_split_impl("mmlf_conv2x2_h2", 2, in, cs_in, K, packed, bias, N, out, cs_out, N_store, out_shift, vh,
+                           vw, B, H, W, relu, relu_ref, cs_ref, in_amax, out_amax, stream);
 }
