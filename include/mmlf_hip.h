@@ -107,6 +107,13 @@ int mmlf_conv2x2_wgrad_split(const float *in, int cs_in, int Cin, const float *g
                              int g_shift, float *gw_oihw, float *gb, int variant, int accumulate,
                              float *workspace, int B, int H, int W, void *stream);
 
+/* f16-split variant of mmlf_conv2x2_wgrad (see mmlf_conv2x2_h2): in_amax / g_amax are device scalars with
+ * max |in| and max |g| */
+int mmlf_conv2x2_wgrad_h2(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout,
+                          int g_shift, float *gw_oihw, float *gb, int variant, int accumulate,
+                          float *workspace, int B, int H, int W, const float *in_amax, const float *g_amax,
+                          void *stream);
+
 /* nn.BatchNorm2d training statistics (feed_forward.py:134): per-channel mean / biased variance of
  * the extent-(H,W) tensor z (zero border), running-stat update (unbiased var), and the affine
  * coefficients scale = gamma*invstd, shift = beta - mean*scale.  partial: 2*C*nblocks doubles. */

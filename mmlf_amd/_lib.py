@@ -27,6 +27,7 @@ SIGNATURES = {
     'mmlf_packed_filter_split_bytes': (_i64, [_i, _i]),
     'mmlf_pack_filter_split': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_conv2x2_split': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    'mmlf_conv2x2_wgrad_h2': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'mmlf_packed_filter_h2_bytes': (_i64, [_i, _i]),
     'mmlf_pack_filter_h2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_conv2x2_h2': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),

@@ -172,7 +172,7 @@ __host__ __device__ __forceinline__ float pow2_scale_for(float amax)
     const int be = (int)((u >> 23) & 0xFF);
     if (be == 0) return 1.f;                       // all-zero (or denormal) tensor
     int e = 268 - be;                              // 2^(14 - floor(log2 amax))
-    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    e = e < 27 ? 27 : (e > 227 ? 227 : e);         // 2^-100 .. 2^100: 1/scale and scale products stay normal
     u = (unsigned)e << 23;
     float r;
     __builtin_memcpy(&r, &u, 4);
@@ -687,6 +687,7 @@ struct WgradArgs {
     float *part;          // [nsplit][4][CIP][NP]
     long long NQpad;
     int cs_in, cin, cs_g, g_shift, P, nsplit, nslice, chunks_per_split, nchunks;
+    const float *in_amax, *g_amax;   // f16 split: max |in|, max |g| (device scalars)
 };
 
 #define WG_KQ 32  // positions per chunk
@@ -828,6 +829,50 @@ __device__ __forceinline__ void split_store4(float4 v, char *p0, int plane_strid
     *reinterpret_cast<uint2 *>(p0 + 2 * plane_stride_bytes) = make_uint2(l0, l1);
 }
 
+// plane-count generic pieces of the weight-gradient kernels: PL = 3 bf16 planes / six cross terms, or
+// PL = 2 f16 planes of the scaled operands / three cross terms (see split2_pair_f16)
+template <int PL>
+__device__ __forceinline__ void split_store4_pl(float4 v, float scale, char *p0, int plane_stride_bytes)
+{
+    if constexpr (PL == 3) {
+        split_store4(v, p0, plane_stride_bytes);
+    } else {
+        unsigned h0, l0, h1, l1;
+        split2_pair_f16(v.x, v.y, scale, h0, l0);
+        split2_pair_f16(v.z, v.w, scale, h1, l1);
+        *reinterpret_cast<uint2 *>(p0) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(p0 + plane_stride_bytes) = make_uint2(l0, l1);
+    }
+}
+template <int PL>
+__device__ __forceinline__ f32x4 mfma16_pl(bf16x8 x, bf16x8 y, f32x4 c)
+{
+    if constexpr (PL == 3) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+}
+// cross terms (activation plane, gradient plane), small ones first
+template <int PL> __device__ __forceinline__ constexpr int term_a(int t)
+{
+    return PL == 3 ? (t == 0 ? 2 : t == 1 ? 0 : t <= 3 ? 1 : 0) : (t == 0 ? 1 : 0);
+}
+template <int PL> __device__ __forceinline__ constexpr int term_b(int t)
+{
+    return PL == 3 ? (t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 1 : 0) : (t == 1 ? 1 : 0);
+}
+// f16 split: what undoes the operand scales for partial-sum row `row` (the ones row carries no input scale)
+struct WgradScales { float sa, sg, inv_sa, inv_sg; };
+template <int PL> __device__ __forceinline__ WgradScales wgrad_scales(const WgradArgs &a)
+{
+    WgradScales s = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (PL == 2) {
+        s.sa = pow2_scale_for(*a.in_amax);
+        s.sg = pow2_scale_for(*a.g_amax);
+        s.inv_sa = 1.f / s.sa;
+        s.inv_sg = 1.f / s.sg;
+    }
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight gradient on v_mfma_f32_16x16x32_bf16 (K = the chunk's 32 positions).  A workgroup owns a slice
 // of 16*MB input channels (MFMA rows, the ones row included) x 16*NB output channels and a split of the
@@ -840,12 +885,14 @@ __device__ __forceinline__ void split_store4(float4 v, char *p0, int plane_strid
 // positions {4q4..4q4+3, 16+4q4..}: the same k permutation for both operands, which a dot product
 // does not see.
 // ---------------------------------------------------------------------------------------------
-template <int MB, int NB>
+template <int MB, int NB, int PL>
 __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
 {
     constexpr int ROWA = 32 * (MB | 1), ROWG = 32 * (NB | 1);   // bytes per position row
     constexpr int A_PLANE = 34 * ROWA;                          // per (seg, plane)
-    constexpr int A_BYTES = 6 * A_PLANE;
+    constexpr int A_BYTES = 2 * PL * A_PLANE;
+    constexpr int NTERM = PL == 3 ? 6 : 3;
+    const WgradScales sc = wgrad_scales<PL>(a);
     constexpr int G_PLANE = WG_KQ * ROWG;
     constexpr int FA = 4 * MB, FG = 4 * NB;                     // float4 per staged row
     constexpr int NA = (66 * FA + 255) / 256, NG = (WG_KQ * FG + 255) / 256;
@@ -908,29 +955,24 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
                 const int seg = row >= 33, pix = row - 33 * seg;                                            \
                 float4 v = ra[j];         /* ones row (bias gradient): patched here, not at load time, */ \
                 const int ch = ci0 + 4 * f; /* so that the global loads issue back to back               */ \
-                if (ch == a.cin) v.x = 1.f;                                                                 \
-                if (ch + 1 == a.cin) v.y = 1.f;                                                             \
-                if (ch + 2 == a.cin) v.z = 1.f;                                                             \
-                if (ch + 3 == a.cin) v.w = 1.f;                                                             \
-                split_store4(v, As + seg * 3 * A_PLANE + pix * ROWA + 8 * f, A_PLANE);                      \
+                if (ch == a.cin) v.x = sc.inv_sa;   /* = 1 after scaling */                                 \
+                if (ch + 1 == a.cin) v.y = sc.inv_sa;                                                       \
+                if (ch + 2 == a.cin) v.z = sc.inv_sa;                                                       \
+                if (ch + 3 == a.cin) v.w = sc.inv_sa;                                                       \
+                split_store4_pl<PL>(v, sc.sa, As + seg * PL * A_PLANE + pix * ROWA + 8 * f, A_PLANE);       \
             }                                                                                               \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
             const int idx = tid + 256 * j;                                                                  \
             if (idx < WG_KQ * FG) {                                                                         \
                 const int row = idx / FG, f = idx - row * FG;                                               \
-                split_store4(rg[j], Gs + row * ROWG + 8 * f, G_PLANE);                                      \
+                split_store4_pl<PL>(rg[j], sc.sg, Gs + row * ROWG + 8 * f, G_PLANE);                        \
             }                                                                                               \
         }                                                                                                   \
     } while (0)
-    // the six cross terms (activation plane, gradient plane), small ones first; independent accumulators
-    // alternate inside each term
-#define WN_PA(term) ((term) == 0 ? 2 : (term) == 1 ? 0 : (term) <= 3 ? 1 : 0)
-#define WN_PB(term) ((term) == 0 ? 0 : (term) == 1 ? 2 : (term) == 2 ? 1 : (term) == 3 ? 0 : (term) == 4 ? 1 : 0)
-
     // transposed-read geometry: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
     const int tq = (lane & 15) >> 2, tp = lane & 3;
-    const char *a_lane = As + (t >> 1) * 3 * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWA + 8 * tp;
+    const char *a_lane = As + (t >> 1) * PL * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWA + 8 * tp;
     const char *g_lane = Gs + (4 * q4 + tq) * ROWG + 8 * tp;
 
     if (c_begin < c_end) {
@@ -940,40 +982,38 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
             __syncthreads();
             if (c + 1 < c_end) WN_GLOAD(c + 1);
             if constexpr (HOLD_G) {
-                bf16x8 gf[NB][3];
+                bf16x8 gf[NB][PL];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) gf[nb][pl] = tr_frag(g_lane + pl * G_PLANE + 32 * nb, 4 * ROWG);
+                    for (int pl = 0; pl < PL; ++pl) gf[nb][pl] = tr_frag(g_lane + pl * G_PLANE + 32 * nb, 4 * ROWG);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    bf16x8 af[3];
+                    bf16x8 af[PL];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) af[pl] = tr_frag(a_lane + pl * A_PLANE + 32 * mb, 4 * ROWA);
+                    for (int pl = 0; pl < PL; ++pl) af[pl] = tr_frag(a_lane + pl * A_PLANE + 32 * mb, 4 * ROWA);
 #pragma unroll
-                    for (int term = 0; term < 6; ++term)
+                    for (int term = 0; term < NTERM; ++term)
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[WN_PA(term)], gf[nb][WN_PB(term)],
-                                                                                  acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = mfma16_pl<PL>(af[term_a<PL>(term)], gf[nb][term_b<PL>(term)], acc[mb][nb]);
                 }
             } else {
-                bf16x8 af[MB][3];
+                bf16x8 af[MB][PL];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) af[mb][pl] = tr_frag(a_lane + pl * A_PLANE + 32 * mb, 4 * ROWA);
+                    for (int pl = 0; pl < PL; ++pl) af[mb][pl] = tr_frag(a_lane + pl * A_PLANE + 32 * mb, 4 * ROWA);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    bf16x8 gf[3];
+                    bf16x8 gf[PL];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) gf[pl] = tr_frag(g_lane + pl * G_PLANE + 32 * nb, 4 * ROWG);
+                    for (int pl = 0; pl < PL; ++pl) gf[pl] = tr_frag(g_lane + pl * G_PLANE + 32 * nb, 4 * ROWG);
 #pragma unroll
-                    for (int term = 0; term < 6; ++term)
+                    for (int term = 0; term < NTERM; ++term)
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][WN_PA(term)], gf[WN_PB(term)],
-                                                                                  acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = mfma16_pl<PL>(af[mb][term_a<PL>(term)], gf[term_b<PL>(term)], acc[mb][nb]);
                 }
             }
             __syncthreads();
@@ -981,8 +1021,6 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
     }
 #undef WN_GLOAD
 #undef WN_LSTORE
-#undef WN_PA
-#undef WN_PB
     constexpr int NP = 16 * NB;
     const int CIP = a.nslice * 16 * MB;
     float *pp = a.part + ((size_t)(split * 4 + t) * CIP + ci0) * NP;
@@ -991,7 +1029,11 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pp[(size_t)(16 * mb + 4 * q4 + r) * NP + 16 * nb + r16] = acc[mb][nb][r];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mb + 4 * q4 + r;      // the ones row (bias gradient) carries no input scale
+                const float un = (ci0 + row == a.cin ? 1.f : sc.inv_sa) * sc.inv_sg;
+                pp[(size_t)row * NP + 16 * nb + r16] = acc[mb][nb][r] * un;
+            }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1002,15 +1044,16 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
 // MFMAs, and chunk c+2's loads are issued.  One barrier per chunk, no phase in which the matrix
 // cores wait for staging.  155.9 KB of LDS: one workgroup per CU.
 // ---------------------------------------------------------------------------------------------
-template <int MB, int NBH>
+template <int MB, int NBH, int PL>
 __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
 {
     constexpr int NB = 2 * NBH;
+    const WgradScales sc = wgrad_scales<PL>(a);
     constexpr int ROWA = 32 * (MB | 1), ROWG = 32 * (NB | 1);
     constexpr int A_PLANE = 34 * ROWA;
-    constexpr int A_BYTES = 6 * A_PLANE;
+    constexpr int A_BYTES = 2 * PL * A_PLANE;
     constexpr int G_PLANE = WG_KQ * ROWG;
-    constexpr int BUF_BYTES = A_BYTES + 3 * G_PLANE;
+    constexpr int BUF_BYTES = A_BYTES + PL * G_PLANE;
     constexpr int FA = 4 * MB, FG = 4 * NB;
     constexpr int NA = (66 * FA + 511) / 512, NG = (WG_KQ * FG + 511) / 512;
     static_assert(2 * BUF_BYTES <= 160 * 1024, "LDS");
@@ -1067,21 +1110,21 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         const int seg = row >= 33, pix = row - 33 * seg;                                                    \
         float4 v = ra[j];                 /* ones row -> bias gradient */                                   \
         const int ch = ci0 + 4 * f;                                                                         \
-        v.x = ch == a.cin ? 1.f : v.x;                                                                      \
-        v.y = ch + 1 == a.cin ? 1.f : v.y;                                                                  \
-        v.z = ch + 2 == a.cin ? 1.f : v.z;                                                                  \
-        v.w = ch + 3 == a.cin ? 1.f : v.w;                                                                  \
-        split_store4(v, (dst) + seg * 3 * A_PLANE + pix * ROWA + 8 * f, A_PLANE);                           \
+        v.x = ch == a.cin ? sc.inv_sa : v.x;   /* = 1 after scaling */                                                                      \
+        v.y = ch + 1 == a.cin ? sc.inv_sa : v.y;                                                                  \
+        v.z = ch + 2 == a.cin ? sc.inv_sa : v.z;                                                                  \
+        v.w = ch + 3 == a.cin ? sc.inv_sa : v.w;                                                                  \
+        split_store4_pl<PL>(v, sc.sa, (dst) + seg * PL * A_PLANE + pix * ROWA + 8 * f, A_PLANE);            \
     } while (0)
 #define WW_STORE_G(j, dst)                                                                                  \
     do {                                                                                                    \
         const int idx = min(tid + 512 * (j), WG_KQ * FG - 1);                                               \
         const int row = idx / FG, f = idx - row * FG;                                                       \
-        split_store4(rg[j], (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);                                 \
+        split_store4_pl<PL>(rg[j], sc.sg, (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);                   \
     } while (0)
 
     const int tq = (lane & 15) >> 2, tp = lane & 3;
-    const int a_off = (t >> 1) * 3 * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWA + 8 * tp;
+    const int a_off = (t >> 1) * PL * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWA + 8 * tp;
     const int g_off = A_BYTES + (4 * q4 + tq) * ROWG + 8 * tp + 32 * NBH * h;
 
     if (c_begin < c_end) {
@@ -1098,32 +1141,28 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         // block, branch-free so that the stores interleave with the MFMAs.
 #define WW_TERM(gf, pa, pb)                                                                                  \
     _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                        \
-        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mb][pa], gf[pb], acc[mb][nb], 0, 0, 0)
+        acc[mb][nb] = mfma16_pl<PL>(af[mb][pa], gf[pb], acc[mb][nb])
 #define WW_CHUNK(STAGE)                                                                                      \
     do {                                                                                                     \
         const char *cur = smem + buf * BUF_BYTES;                                                            \
         char *nxt = smem + (buf ^ 1) * BUF_BYTES;                                                            \
-        bf16x8 af[MB][3], gfr[2][3];                                                                         \
-        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                     \
+        bf16x8 af[MB][PL], gfr[2][PL];                                                                         \
+        _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                                     \
             gfr[0][pl] = tr_frag(cur + g_off + pl * G_PLANE, 4 * ROWG);                                      \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                    \
-            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                 \
+            _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                                 \
                 af[mb][pl] = tr_frag(cur + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);                        \
         _Pragma("unroll") for (int nb = 0; nb < NBH; ++nb) {                                                 \
             if (nb + 1 < NBH) {                                                                              \
-                _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                             \
+                _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                             \
                     gfr[(nb + 1) & 1][pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * (nb + 1), 4 * ROWG);   \
             }                                                                                                \
             if (STAGE) {                                                                                     \
                 if (nb < NA) WW_STORE_A(nb < NA ? nb : 0, nxt);                                              \
                 else if (nb - NA < NG) WW_STORE_G(nb - NA < NG ? nb - NA : 0, nxt);                          \
             }                                                                                                \
-            WW_TERM(gfr[nb & 1], 2, 0);                                                                      \
-            WW_TERM(gfr[nb & 1], 0, 2);                                                                      \
-            WW_TERM(gfr[nb & 1], 1, 1);                                                                      \
-            WW_TERM(gfr[nb & 1], 1, 0);                                                                      \
-            WW_TERM(gfr[nb & 1], 0, 1);                                                                      \
-            WW_TERM(gfr[nb & 1], 0, 0);                                                                      \
+            _Pragma("unroll") for (int term = 0; term < (PL == 3 ? 6 : 3); ++term)                           \
+                WW_TERM(gfr[nb & 1], term_a<PL>(term), term_b<PL>(term));                                    \
         }                                                                                                    \
     } while (0)
         static_assert(NA + NG <= NBH, "one staging piece per column block");
@@ -1148,7 +1187,11 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
 #pragma unroll
         for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pp[(size_t)(16 * mb + 4 * q4 + r) * NP + 16 * nb + r16] = acc[mb][nb][r];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mb + 4 * q4 + r;      // the ones row (bias gradient) carries no input scale
+                const float un = (ci0 + row == a.cin ? 1.f : sc.inv_sa) * sc.inv_sg;
+                pp[(size_t)row * NP + 16 * nb + r16] = acc[mb][nb][r] * un;
+            }
 }
 
 // sum the position splits and scatter to the OIHW master gradient (+ bias gradient)
@@ -1304,36 +1347,51 @@ static int launch_wgrad(const WgradArgs &a, hipStream_t st)
     return mmlf_launch_status("mmlf_conv2x2_wgrad");
 }
 
-template <int MB, int NB>
+template <int MB, int NB, int PL>
 static int launch_wgrad16(const WgradArgs &a, hipStream_t st)
 {
-    constexpr size_t lds = 6 * 34 * 32 * (MB | 1) + 3 * WG_KQ * 32 * (NB | 1);
+    constexpr size_t lds = 2 * PL * 34 * 32 * (MB | 1) + PL * WG_KQ * 32 * (NB | 1);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6n_kernel<MB, NB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6n_kernel<MB, NB, PL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad4tap_x6n_kernel<MB, NB>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((wgrad4tap_x6n_kernel<MB, NB, PL>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(256), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
 }
 
+template <int PL>
 static int launch_wgrad_wide(const WgradArgs &a, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (6 * 34 * 32 * (3 | 1) + 3 * WG_KQ * 32 * (18 | 1));
+    constexpr size_t lds = 2 * (2 * PL * 34 * 32 * (3 | 1) + PL * WG_KQ * 32 * (18 | 1));
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6w_kernel<3, 9>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6w_kernel<3, 9, PL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wgrad4tap_x6w_kernel<3, 9>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((wgrad4tap_x6w_kernel<3, 9, PL>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(512), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
 }
 
+template <int PL>
+static int launch_wgrad_split(const Wgrad16Cfg &c, const WgradArgs &a, hipStream_t st)
+{
+    switch (10 * c.mb + c.nb) {
+    case 22: return launch_wgrad16<2, 2, PL>(a, st);
+    case 52: return launch_wgrad16<5, 2, PL>(a, st);
+    case 25: return launch_wgrad16<2, 5, PL>(a, st);
+    case 55: return launch_wgrad16<5, 5, PL>(a, st);
+    case 28: return launch_wgrad16<2, 8, PL>(a, st);
+    default: return launch_wgrad_wide<PL>(a, st);
+    }
+}
+
+// planes: 0 = exact-f32 MFMA, 3 = bf16 split, 2 = f16 split (needs in_amax / g_amax)
 static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout, int g_shift,
                       float *gw, float *gb, int variant, int accumulate, float *workspace, int B, int H, int W,
-                      void *stream, int split_bf16);
+                      void *stream, int planes, const float *in_amax = nullptr, const float *g_amax = nullptr);
 
 extern "C" int mmlf_conv2x2_wgrad(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout,
                                   int g_shift, float *gw, float *gb, int variant, int accumulate,
@@ -1348,12 +1406,22 @@ extern "C" int mmlf_conv2x2_wgrad_split(const float *in, int cs_in, int Cin, con
                                         float *workspace, int B, int H, int W, void *stream)
 {
     return wgrad_impl(in, cs_in, Cin, g, cs_g, Cout, g_shift, gw, gb, variant, accumulate, workspace, B, H, W,
-                      stream, 1);
+                      stream, 3);
+}
+
+extern "C" int mmlf_conv2x2_wgrad_h2(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout,
+                                     int g_shift, float *gw, float *gb, int variant, int accumulate,
+                                     float *workspace, int B, int H, int W, const float *in_amax,
+                                     const float *g_amax, void *stream)
+{
+    MMLF_CHECK_ARG(in_amax && g_amax, "mmlf_conv2x2_wgrad_h2: the f16 split needs max |in| and max |g|");
+    return wgrad_impl(in, cs_in, Cin, g, cs_g, Cout, g_shift, gw, gb, variant, accumulate, workspace, B, H, W,
+                      stream, 2, in_amax, g_amax);
 }
 
 static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout, int g_shift,
                       float *gw, float *gb, int variant, int accumulate, float *workspace, int B, int H, int W,
-                      void *stream, int split_bf16)
+                      void *stream, int planes, const float *in_amax, const float *g_amax)
 {
     MMLF_CHECK_ARG(in && g && gw && workspace, "mmlf_conv2x2_wgrad: null pointer");
     MMLF_CHECK_ARG(cs_in % 4 == 0 && cs_g % 4 == 0, "mmlf_conv2x2_wgrad: strides must be multiples of 4");
@@ -1366,6 +1434,7 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
     WgradArgs a;
     a.in = in; a.g = g; a.part = workspace; a.NQpad = gr.NQpad;
     a.cs_in = cs_in; a.cin = Cin; a.cs_g = cs_g; a.g_shift = g_shift; a.P = gr.P;
+    a.in_amax = in_amax; a.g_amax = g_amax;
     a.nslice = (Cin + 1 + 31) / 32;   // +1: the ones row that yields the bias gradient
     a.nsplit = wgrad_nsplit(a.nslice);
     a.nchunks = (int)(gr.NQpad / WG_KQ);
@@ -1373,18 +1442,11 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
     hipStream_t st = (hipStream_t)stream;
     int rc;
     Wgrad16Cfg c;
-    if (split_bf16 && wgrad16_cfg(Cin, Cout, &c)) {
+    if (planes && wgrad16_cfg(Cin, Cout, &c)) {
         a.nslice = c.nslice;
         a.nsplit = c.nsplit;
         a.chunks_per_split = (a.nchunks + a.nsplit - 1) / a.nsplit;
-        switch (10 * c.mb + c.nb) {
-        case 22: rc = launch_wgrad16<2, 2>(a, st); break;
-        case 52: rc = launch_wgrad16<5, 2>(a, st); break;
-        case 25: rc = launch_wgrad16<2, 5>(a, st); break;
-        case 55: rc = launch_wgrad16<5, 5>(a, st); break;
-        case 28: rc = launch_wgrad16<2, 8>(a, st); break;
-        default: rc = launch_wgrad_wide(a, st); break;
-        }
+        rc = planes == 3 ? launch_wgrad_split<3>(c, a, st) : launch_wgrad_split<2>(c, a, st);
         if (rc) return rc;
         const int total = 4 * (Cin + 1) * Cout;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw, gb, Cin,
