@@ -133,7 +133,8 @@ int mmlf_fold_bn_eval(const float *w_oihw, const float *bias, const float *scale
 /* y[q][c_off + c] = interior(q) ? relu(z[q][c]*scale[c] + shift[c]) : 0   (BN apply + nn.ReLU,
  * feed_forward.py:134-135; writing a channel slice implements torch.cat, feed_forward.py:266-267) */
 int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *scale, const float *shift,
-                       float *y, int cs_y, int c_off, int C_store, int B, int H, int W, void *stream);
+                       float *y, int cs_y, int c_off, int C_store, int B, int H, int W,
+                       float *amax_out /* nullable: atomic max |y| into a device scalar */, void *stream);
 /* BatchNorm2d + ReLU backward, pass 1: per-channel sums of g and g*zhat with
  * g = gy * (z*scale+shift > 0); emits dgamma, dbeta (accumulating) and coefficients k[3*C]. */
 int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
@@ -144,11 +145,13 @@ int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const float *z, in
 /* pass 2: dz[q][c] = interior(q) ? k1*g - k2 - k3*(z - mean) : 0 */
 int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
                       const float *scale, const float *shift, const float *save_mean,
-                      const float *coef, float *dz, int cs_dz, int B, int H, int W, void *stream);
+                      const float *coef, float *dz, int cs_dz, int B, int H, int W,
+                      float *amax_out /* nullable: atomic max |dz| */, void *stream);
 
 /* (B, C, H, W) NCHW  <->  padded-grid NHWC (extent (H,W), grid offset (1,1), zero border, zero pad
  * channels).  replaces the .view / layout handling of feed_forward.py:226-232 and output[:, 0]. */
-int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int B, int H, int W, void *stream);
+int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int B, int H, int W,
+                   float *amax_out /* nullable: atomic max |x| */, void *stream);
 int mmlf_unpack_nchw(const float *grid, int cs, float *nchw, int C, int B, int H, int W, void *stream);
 
 /* UPR head (feed_forward.py:292-302, laplacian :9-12): posterior[b,k,y,x] from output[:,0:2]. */

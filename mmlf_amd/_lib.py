@@ -36,10 +36,10 @@ SIGNATURES = {
     'mmlf_bn_stats_train': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_bn_coeffs_eval': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _vp]),
     'mmlf_fold_bn_eval': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    'mmlf_bn_apply_relu': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mmlf_bn_apply_relu': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'mmlf_bn_bwd_reduce': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'mmlf_bn_bwd_apply': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'mmlf_pack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_bn_bwd_apply': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'mmlf_pack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     'mmlf_unpack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_head_upr': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_head_dpp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

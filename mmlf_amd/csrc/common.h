@@ -68,3 +68,16 @@ __host__ __device__ static inline int master_tap(int t, int variant)
     if (variant == 1) return dx * 2 + dy;         // transpose
     return dx * 2 + (1 - dy);                     // transpose, then flip along kernel-H
 }
+
+// Running max |x| of a tensor in a device scalar (non-negative floats order like their bit patterns).
+// Every thread of the block calls it with its own maximum; the atomic is skipped when the scalar already
+// holds a larger value (a stale read only costs an extra atomic), so a launch issues few of them.
+__device__ __forceinline__ void mmlf_amax_update(float m, float *amax)
+{
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned bits = __float_as_uint(m);
+        unsigned *slot = reinterpret_cast<unsigned *>(amax);
+        if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    }
+}

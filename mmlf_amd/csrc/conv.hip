@@ -534,10 +534,7 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
         __syncthreads();
         buf ^= 1;
     }
-    if (a.out_amax) {                      // one atomic per wave per launch
-        for (int o = 32; o > 0; o >>= 1) run_max = fmaxf(run_max, __shfl_xor(run_max, o));
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.out_amax), __float_as_uint(run_max));
-    }
+    if (a.out_amax) mmlf_amax_update(run_max, a.out_amax);      // at most one atomic per wave per launch
 #undef X6_DMA_PIECE
 #undef X6_DMA_SLOT
 #undef X6_DMA_WAIT

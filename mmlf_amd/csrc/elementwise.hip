@@ -7,7 +7,7 @@
 thread_local char g_mmlf_err[512] = "";
 
 extern "C" const char *mmlf_last_error(void) { return g_mmlf_err; }
-extern "C" int mmlf_abi_version(void) { return 1; }
+extern "C" int mmlf_abi_version(void) { return 2; }
 extern "C" int64_t mmlf_grid_alloc_positions(int B, int H, int W)
 {
     if (B <= 0 || H <= 0 || W <= 0) return -1;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
                                                       const float *__restrict__ mean,
                                                       const float *__restrict__ coef, int C,
                                                       float *__restrict__ out, int cs_out, int c_off_out,
-                                                      int C_store, int H, int W)
+                                                      int C_store, int H, int W, float *__restrict__ amax)
 {
     // one block per grid row; a thread walks (position, channel group) pairs with stride 256 without
     // divisions: (x, cg) += (256 / cvn, 256 % cvn) with carry.  Per-channel coefficients sit in LDS.
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
     const bool row_in = (y >= 1 && y <= H);
     const int dx = 256 / cvn, dc = 256 - dx * cvn;
     int x = threadIdx.x / cvn, cg = threadIdx.x - x * cvn;
+    float mx = 0.f;
     for (; x < P; x += dx, cg += dc) {
         if (cg >= cvn) { cg -= cvn; ++x; if (x >= P) break; }
         float o[V];
@@ -258,6 +259,8 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
                 }
             }
         }
+#pragma unroll
+        for (int k = 0; k < V; ++k) mx = fmaxf(mx, fabsf(o[k]));
         float *op = out + (base + x) * cs_out + c_off_out + V * cg;
         if (V * cg + V - 1 < C_store) {
             VecIO<V>::store(op, o);
@@ -267,12 +270,15 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
                 if (V * cg + k < C_store) op[k] = o[k];
         }
     }
+    if (amax) mmlf_amax_update(mx, amax);
 }
 
 // NCHW <-> grid
 __global__ __launch_bounds__(256) void pack_nchw_kernel(const float *__restrict__ src, int C,
-                                                        float *__restrict__ grid, int cs, int H, int W)
+                                                        float *__restrict__ grid, int cs, int H, int W,
+                                                        float *__restrict__ amax)
 {
+    float mx = 0.f;
     const int P = W + 2, R = H + 2;
     const int row = blockIdx.x;
     const int b = row / R, y = row - b * R;
@@ -289,8 +295,10 @@ __global__ __launch_bounds__(256) void pack_nchw_kernel(const float *__restrict_
                 if (c < C) o[k] = src[(((size_t)b * C + c) * H + (y - 1)) * W + (x - 1)];
             }
         }
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         *reinterpret_cast<float4 *>(grid + (base + x) * cs + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
     }
+    if (amax) mmlf_amax_update(mx, amax);
 }
 
 __global__ __launch_bounds__(256) void unpack_nchw_kernel(const float *__restrict__ grid, int cs,
@@ -821,7 +829,8 @@ extern "C" int mmlf_fold_bn_eval(const float *w_oihw, const float *bias, const f
 }
 
 extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *scale, const float *shift, float *y,
-                                  int cs_y, int c_off, int C_store, int B, int H, int W, void *stream)
+                                  int cs_y, int c_off, int C_store, int B, int H, int W, float *amax_out,
+                                  void *stream)
 {
     MMLF_CHECK_ARG(z && scale && shift && y, "mmlf_bn_apply_relu: null pointer");
     MMLF_CHECK_ARG(cs_z % 4 == 0 && cs_y % 2 == 0 && c_off % 2 == 0 && C <= cs_z && C_store >= C &&
@@ -829,10 +838,10 @@ extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *
                    "mmlf_bn_apply_relu: C=%d cs_z=%d cs_y=%d c_off=%d C_store=%d", C, cs_z, cs_y, c_off, C_store);
     if (cs_y % 4 == 0 && c_off % 4 == 0)
         hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
-                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W);
+                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out);
     else
         hipLaunchKernelGGL((bn_rows_kernel<0, 2>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
-                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W);
+                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out);
     return mmlf_launch_status("mmlf_bn_apply_relu");
 }
 
@@ -861,24 +870,26 @@ extern "C" int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const f
 
 extern "C" int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
                                  const float *scale, const float *shift, const float *save_mean, const float *coef,
-                                 float *dz, int cs_dz, int B, int H, int W, void *stream)
+                                 float *dz, int cs_dz, int B, int H, int W, float *amax_out, void *stream)
 {
     MMLF_CHECK_ARG(gy && z && scale && shift && save_mean && coef && dz, "mmlf_bn_bwd_apply: null pointer");
     MMLF_CHECK_ARG(cs_gy % 2 == 0 && c_off % 2 == 0 && cs_z % 4 == 0 && cs_dz % 4 == 0 && C <= cs_dz,
                    "mmlf_bn_bwd_apply: layout");
     if (cs_gy % 4 == 0 && c_off % 4 == 0)
         hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
-                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W);
+                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out);
     else
         hipLaunchKernelGGL((bn_rows_kernel<1, 2>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
-                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W);
+                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out);
     return mmlf_launch_status("mmlf_bn_bwd_apply");
 }
 
-extern "C" int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int B, int H, int W, void *stream)
+extern "C" int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int B, int H, int W, float *amax_out,
+                              void *stream)
 {
     MMLF_CHECK_ARG(nchw && grid && C > 0 && cs % 4 == 0 && C <= cs, "mmlf_pack_nchw: C=%d cs=%d", C, cs);
-    hipLaunchKernelGGL(pack_nchw_kernel, dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, nchw, C, grid, cs, H, W);
+    hipLaunchKernelGGL(pack_nchw_kernel, dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, nchw, C, grid, cs, H, W,
+                       amax_out);
     return mmlf_launch_status("mmlf_pack_nchw");
 }
 

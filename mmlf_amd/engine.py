@@ -31,12 +31,22 @@ class Geometry:
         self.alloc = int(_lib.load().mmlf_grid_alloc_positions(B, H, W))
         if self.alloc * 288 * 4 >= 2 ** 63 or self.NQ + 600 >= 2 ** 31:
             raise ValueError('batch x image too large for 32-bit grid positions')
+        self._amax_pool, self._amax_used = None, 0
+
+    def _amax_slot(self, device):
+        """A zeroed device scalar: the running max |x| of one grid tensor (its producers raise it by atomic
+        max; the f16-split kernels derive the tensor's power-of-two scale from it)."""
+        if self._amax_pool is None or self._amax_used == self._amax_pool.numel():
+            self._amax_pool, self._amax_used = torch.zeros(256, dtype=torch.float32, device=device), 0
+        self._amax_used += 1
+        return self._amax_pool[self._amax_used - 1:self._amax_used]
 
     def buf(self, cs, device):
         """Grid buffer with zeroed head/tail slack (the kernels write everything else)."""
         t = torch.empty(self.alloc * cs, dtype=torch.float32, device=device)
         t[:(self.P + 1) * cs].zero_()
         t[self.NQ * cs:].zero_()
+        t.absmax = self._amax_slot(device)
         return t
 
 
@@ -66,13 +76,21 @@ class _Workspace:
         return self.wgrad
 
 
-# 'bf16x6': split-precision MFMA (f32-equivalent accuracy, 2.67x the f32 MFMA rate); 'f32': exact-f32 MFMA
+# 'f16x3': 2-way f16 split of power-of-two-scaled operands, 3 MFMA passes (f32-equivalent accuracy, 5.3x the
+# f32 MFMA rate); 'bf16x6': 3-way bf16 split, 6 passes (no operand scaling needed); 'f32': exact-f32 MFMA
 CONV_MODE = os.environ.get('MMLF_CONV_MODE', 'bf16x6')
 
 
 def pack_filter(w, variant, dgrad):
     cout, cin = w.shape[0], w.shape[1]
     K, N = (cout, cin) if dgrad else (cin, cout)
+    if CONV_MODE == 'f16x3':
+        n = int(_lib.load().mmlf_packed_filter_h2_bytes(cs_of(K), N))
+        if n < 0:
+            raise RuntimeError(f'pack_filter: unsupported channels K={K} N={N}')
+        out = torch.empty(n // 4, dtype=torch.float32, device=w.device)
+        call('mmlf_pack_filter_h2', ptr(w), ptr(out), cout, cin, variant, int(dgrad), _lib.stream_ptr())
+        return out
     if CONV_MODE == 'bf16x6':
         n = int(_lib.load().mmlf_packed_filter_split_bytes(cs_of(K), N))
         if n < 0:
@@ -93,15 +111,37 @@ def pack_filter(w, variant, dgrad):
 PROFILE = None   # bench.py sets this to a list to time the dominant conv launches with HIP events
 
 
+def _amax_of(t):
+    """The device scalar with max |t| that the f16-split kernels scale by.  Grid tensors made by
+    Geometry.buf carry it (their producers maintain it); for any other tensor it is computed here."""
+    a = getattr(t, 'absmax', None)
+    return a if a is not None else t.abs().max().reshape(1)
+
+
+def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace):
+    """weight + bias gradient, accumulated into gw / gb"""
+    args = (ptr(x), cs_in, cin, ptr(g), cs_g, cout, g_shift, ptr(gw), ptr(gb), variant, 1, ptr(workspace),
+            geo.B, geo.H, geo.W)
+    if CONV_MODE == 'f16x3':
+        ax, ag = _amax_of(x), _amax_of(g)
+        call('mmlf_conv2x2_wgrad_h2', *args, ptr(ax), ptr(ag), _lib.stream_ptr())
+    else:
+        call('mmlf_conv2x2_wgrad_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad', *args, _lib.stream_ptr())
+
+
 def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0,
          n_store=None, out_off=0):
     prof = PROFILE is not None and K >= 256 and N >= 256
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call('mmlf_conv2x2_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2', ptr(x), cs_in, K, ptr(packed), ptr(bias), N,
-         ptr(out) + 4 * out_off, cs_out, cs_out if n_store is None else n_store, out_shift,
-         vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref, _lib.stream_ptr())
+    args = (ptr(x), cs_in, K, ptr(packed), ptr(bias), N, ptr(out) + 4 * out_off, cs_out,
+            cs_out if n_store is None else n_store, out_shift, vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref)
+    if CONV_MODE == 'f16x3':
+        ax = _amax_of(x)
+        call('mmlf_conv2x2_h2', *args, ptr(ax), ptr(getattr(out, 'absmax', None)), _lib.stream_ptr())
+    else:
+        call('mmlf_conv2x2_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2', *args, _lib.stream_ptr())
     if prof:
         e1.record()
         # algorithmic FLOPs of this launch: valid output positions x N x 4 taps x K, 2 FLOP per MAC
@@ -192,7 +232,7 @@ class Trunk:
         else:
             c_store = C
         call('mmlf_bn_apply_relu', ptr(z), cs_mid, C, ptr(scale), ptr(shift), ptr(out), cs_out, c_off, c_store,
-             B, H, W, _lib.stream_ptr())
+             B, H, W, ptr(out.absmax), _lib.stream_ptr())
         rec.update(scale=scale, shift=shift, smean=smean, sinv=sinv)
         if rec_list is not None:
             rec_list.append(rec)
@@ -210,7 +250,7 @@ class Trunk:
         concat = geo.buf(4 * self.chs, dev)
         for s, (key, var, blocks) in enumerate(self.streams):
             x = geo.buf(cs_of(cin0), dev)
-            call('mmlf_pack_nchw', ptr(stacks[s]), cin0, ptr(x), cs_of(cin0), B, H, W, _lib.stream_ptr())
+            call('mmlf_pack_nchw', ptr(stacks[s]), cin0, ptr(x), cs_of(cin0), B, H, W, ptr(x.absmax), _lib.stream_ptr())
             cs_x = cs_of(cin0)
             recs = []
             for k, spec in enumerate(blocks):
@@ -247,22 +287,21 @@ class Trunk:
                  ptr(grads[f'{pre}.3.bias']), 1, ptr(coef), ptr(ws.partial), BN_BLOCKS, B, H, W, sp())
             dz = geo.buf(cs_mid, dev)
             call('mmlf_bn_bwd_apply', ptr(gy), cs_gy, c_off, ptr(z), cs_mid, C, ptr(rec['scale']), ptr(rec['shift']),
-                 ptr(rec['smean']), ptr(coef), ptr(dz), cs_mid, B, H, W, sp())
+                 ptr(rec['smean']), ptr(coef), ptr(dz), cs_mid, B, H, W, ptr(dz.absmax), sp())
         else:
             assert c_off == 0 and cs_gy == cs_mid
             dz = gy
         w1, w2 = p[f'{pre}.0.weight'], p[f'{pre}.2.weight']
         # conv2 (pad 0): weight/bias gradient, then data gradient fused with the ReLU mask of y
-        wg = 'mmlf_conv2x2_wgrad_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad'
-        call(wg, ptr(y), cs_mid, C, ptr(dz), cs_mid, C, P + 1, ptr(grads[f'{pre}.2.weight']),
-             ptr(grads[f'{pre}.2.bias']), var, 1, ptr(ws.wgrad_ws(C, C)), B, H, W, sp())
+        wgrad(geo, y, cs_mid, C, dz, cs_mid, C, P + 1, grads[f'{pre}.2.weight'], grads[f'{pre}.2.bias'], var,
+              ws.wgrad_ws(C, C))
         pk = pack_filter(w2, var, True)
         dy = geo.buf(cs_mid, dev)
         conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
         del dz
         # conv1 (pad 1)
-        call(wg, ptr(x), cs_x, spec.cin, ptr(dy), cs_mid, C, 0, ptr(grads[f'{pre}.0.weight']),
-             ptr(grads[f'{pre}.0.bias']), var, 1, ptr(ws.wgrad_ws(spec.cin, C)), B, H, W, sp())
+        wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'], var,
+              ws.wgrad_ws(spec.cin, C))
         if not need_dx:
             return None
         pk = pack_filter(w1, var, True)
@@ -279,7 +318,8 @@ class Trunk:
         B, H, W = geo.B, geo.H, geo.W
         cs = cs_of(self.oc)
         g = geo.buf(cs, dev)
-        call('mmlf_pack_nchw', ptr(grad_output.contiguous()), self.oc, ptr(g), cs, B, H, W, _lib.stream_ptr())
+        call('mmlf_pack_nchw', ptr(grad_output.contiguous()), self.oc, ptr(g), cs, B, H, W, ptr(g.absmax),
+             _lib.stream_ptr())
         cs_g = cs
         recs = tape['out']
         while recs:

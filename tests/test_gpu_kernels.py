@@ -31,7 +31,7 @@ CONV_SHAPES = [(27, 70), (70, 70), (280, 280), (280, 1), (2, 2), (280, 108), (10
 
 @pytest.mark.parametrize('cin,cout', CONV_SHAPES)
 @pytest.mark.parametrize('pad', [1, 0])
-@pytest.mark.parametrize('mode', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'f16x3'])
 def test_conv_forward_and_border(oracle, cin, cout, pad, mode, monkeypatch):
     from mmlf_amd import engine
     monkeypatch.setattr(engine, 'CONV_MODE', mode)
@@ -69,7 +69,7 @@ def test_conv_forward_and_border(oracle, cin, cout, pad, mode, monkeypatch):
         assert not full.reshape(geo.alloc, cs_out)[geo.NQ:].any()
 
 
-@pytest.mark.parametrize('mode', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('B,H,W', [(1, 3, 400), (1, 1, 1), (2, 2, 700), (5, 96, 96)])
 def test_conv_wide_and_degenerate_frames(oracle, mode, B, H, W, monkeypatch):
     """Pitch > 383 switches the split kernel to its two-segment activation window; 1x1 images and a
@@ -127,7 +127,7 @@ def test_filter_variants_equal_image_transforms(oracle, variant):
 @pytest.mark.parametrize('cin,cout', [(27, 70), (70, 70), (280, 280), (280, 2), (2, 2), (280, 108), (32, 8), (79, 80), (31, 33)])
 @pytest.mark.parametrize('pad', [1, 0])
 @pytest.mark.parametrize('variant', [0, 2])
-@pytest.mark.parametrize('mode', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'f16x3'])
 def test_conv_backward(oracle, cin, cout, pad, variant, mode, monkeypatch):
     """data gradient (with fused ReLU mask), weight and bias gradients vs the oracle."""
     from mmlf_amd import engine, _lib
@@ -160,8 +160,7 @@ def test_conv_backward(oracle, cin, cout, pad, variant, mode, monkeypatch):
     tgw = torch.full((cout, cin, 2, 2), 0.5, device=dev)
     tgb = torch.full((cout,), -0.25, device=dev)
     ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout)), device=dev)
-    call('mmlf_conv2x2_wgrad_split' if mode == 'bf16x6' else 'mmlf_conv2x2_wgrad', ptr(xg), cs_in, cin, ptr(gg),
-         cs_out, cout, fwd_shift, ptr(tgw), ptr(tgb), variant, 1, ptr(ws), B, H, W, _lib.stream_ptr())
+    engine.wgrad(geo, xg, cs_in, cin, gg, cs_out, cout, fwd_shift, tgw, tgb, variant, ws)
     scale = np.abs(gw).max()
     np.testing.assert_allclose(tgw.cpu().numpy() - 0.5, gw, rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(tgb.cpu().numpy() + 0.25, gb, rtol=1e-4, atol=2e-5 * np.abs(gb).max())
@@ -202,10 +201,12 @@ def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
     np.testing.assert_allclose(trv.cpu().numpy(), rv_o, rtol=2e-6)
     y = torch.full((geo.alloc * cs_y,), 7.0, device=dev)
     c_store = C if cs_y != cs else cs
+    amax = torch.zeros(1, device=dev)
     call('mmlf_bn_apply_relu', ptr(zg), cs, C, ptr(coef), ptr(coef[C:]), ptr(y), cs_y, c_off, c_store, B, H, W,
-         _lib.stream_ptr())
+         ptr(amax), _lib.stream_ptr())
     full = y.cpu().numpy().reshape(geo.alloc, cs_y)
     got, g = nchw_from_grid(full.reshape(-1), cs_y, cs_y, geo, H, W, 1)
+    assert float(amax) == float(got[:, c_off:c_off + C].max())       # the running max |y| the f16 split scales by
     np.testing.assert_allclose(got[:, c_off:c_off + C], y_ref, rtol=1e-5, atol=2e-6)
     assert (g[:, 0, :, c_off:c_off + C] == 0).all() and (g[:, :, 0, c_off:c_off + C] == 0).all()
     other = np.delete(full[:geo.NQ], np.s_[c_off:c_off + c_store], axis=1)
@@ -231,8 +232,10 @@ def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
     call('mmlf_bn_bwd_reduce', ptr(gyg), cs_y, c_off, ptr(zg), cs, C, ptr(coef), ptr(coef[C:]), ptr(tg),
          ptr(coef[2 * C:]), ptr(coef[3 * C:]), ptr(dgam), ptr(dbet), 1, ptr(k), ptr(part), 1024, B, H, W, _lib.stream_ptr())
     dz = torch.full((geo.alloc * cs,), float('nan'), device=dev)
+    amax.zero_()
     call('mmlf_bn_bwd_apply', ptr(gyg), cs_y, c_off, ptr(zg), cs, C, ptr(coef), ptr(coef[C:]), ptr(coef[2 * C:]),
-         ptr(k), ptr(dz), cs, B, H, W, _lib.stream_ptr())
+         ptr(k), ptr(dz), cs, B, H, W, ptr(amax), _lib.stream_ptr())
+    assert float(amax) == float(dz[:geo.NQ * cs].abs().max())
     np.testing.assert_allclose(dgam.cpu().numpy() - 1, gg_ref, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(dbet.cpu().numpy() - 1, gb_ref, rtol=1e-4, atol=1e-4)
     got, g = nchw_from_grid(dz.cpu().numpy(), cs, C, geo, H, W, 1)
@@ -250,7 +253,9 @@ def test_pack_unpack_roundtrip():
     x = rs.uniform(-1, 1, (B, C, H, W)).astype(np.float32)
     g = torch.full((geo.alloc * 32,), float('nan'), device=dev)
     g[geo.NQ * 32:] = 0
-    call('mmlf_pack_nchw', ptr(torch.from_numpy(x).to(dev)), C, ptr(g), 32, B, H, W, _lib.stream_ptr())
+    amax = torch.zeros(1, device=dev)
+    call('mmlf_pack_nchw', ptr(torch.from_numpy(x).to(dev)), C, ptr(g), 32, B, H, W, ptr(amax), _lib.stream_ptr())
+    assert float(amax) == float(np.abs(x).max())
     np.testing.assert_array_equal(g.cpu().numpy(), grid_from_nchw(x, 32, geo))
     back = torch.empty((B, C, H, W), device=dev)
     call('mmlf_unpack_nchw', ptr(g), 32, ptr(back), C, B, H, W, _lib.stream_ptr())
@@ -273,13 +278,14 @@ def test_error_convention():
              None, 0, None)
 
 
+@pytest.mark.parametrize('mode', ['bf16x6', 'f16x3'])
 @pytest.mark.parametrize('cin,cout,pad', [(280, 280, 1), (280, 280, 0), (70, 70, 1), (27, 70, 1)])
-def test_full_size_adjoint_identities(cin, cout, pad):
+def test_full_size_adjoint_identities(cin, cout, pad, mode, monkeypatch):
     """BASELINE.json's full size (bs=512, ps=96), where the oracle is too slow: the three conv kernels must be
     each other's adjoints, <conv(x; W), g> = <x, dgrad(g; W)> = <W, wgrad(x, g)> (+ bias term), which does
     not depend on the size.  Inputs live directly on the padded grid (device-side random, zero borders)."""
     from mmlf_amd import engine, _lib
-    from mmlf_amd._lib import call, ptr
+    monkeypatch.setattr(engine, 'CONV_MODE', mode)
     dev = _dev()
     B, H, W = 512, 96, 96
     geo = engine.Geometry(B, H, W)
@@ -307,8 +313,7 @@ def test_full_size_adjoint_identities(cin, cout, pad):
     gw = torch.zeros_like(w)
     gb = torch.zeros(cout, device=dev)
     ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout)), device=dev)
-    call('mmlf_conv2x2_wgrad_split' if engine.CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad', ptr(x), cs_in, cin,
-         ptr(g), cs_out, cout, fwd_shift, ptr(gw), ptr(gb), 0, 0, ptr(ws), B, H, W, _lib.stream_ptr())
+    engine.wgrad(geo, x, cs_in, cin, g, cs_out, cout, fwd_shift, gw, gb, 0, ws)
     lhs = torch.dot(out.double(), g.double())
     via_x = torch.dot(x.double(), dx.double()) + torch.dot(bias.double(), gb.double())
     via_w = torch.dot(w.double().reshape(-1), gw.double().reshape(-1)) + torch.dot(bias.double(), gb.double())
@@ -321,7 +326,7 @@ def test_full_size_adjoint_identities(cin, cout, pad):
 
 
 def test_split_arithmetic_is_at_f32_accuracy():
-    """The default split-precision kernels must not be a precision downgrade: against a float64 evaluation
+    """The split-precision kernels (bf16 3-way / six passes, f16 2-way / three passes) must not be a precision downgrade: against a float64 evaluation
     of the same convolution (K = 4 x 280 products per output, the dominant layer) their error is no larger
     than that of the exact-f32 MFMA kernels."""
     from mmlf_amd import engine
@@ -343,7 +348,7 @@ def test_split_arithmetic_is_at_f32_accuracy():
             mag += np.einsum('bchw,oc->bohw', np.abs(patch), np.abs(w[:, :, dy, dx]).astype(np.float64))
     xg = torch.from_numpy(grid_from_nchw(x, cs, geo, offset=1)).to(dev)
     err = {}
-    for mode in ('f32', 'bf16x6'):
+    for mode in ('f32', 'bf16x6', 'f16x3'):
         engine.CONV_MODE, keep = mode, engine.CONV_MODE
         try:
             pk = engine.pack_filter(torch.from_numpy(w).to(dev), 0, False)
@@ -354,6 +359,7 @@ def test_split_arithmetic_is_at_f32_accuracy():
         got, _ = nchw_from_grid(out.cpu().numpy(), cs, cout, geo, H + 1, W + 1, 0)
         rel = np.abs(got.astype(np.float64) - ref) / mag
         err[mode] = (rel.mean(), rel.max())
-    assert err['bf16x6'][0] <= 1.1 * err['f32'][0], err       # mean error relative to sum|a*b|
-    assert err['bf16x6'][1] <= 1.5 * err['f32'][1], err       # worst element
-    assert err['f32'][0] < 5e-8 and err['bf16x6'][0] < 5e-8, err
+    for mode in ('bf16x6', 'f16x3'):
+        assert err[mode][0] <= 1.1 * err['f32'][0], err           # mean error relative to sum|a*b|
+        assert err[mode][1] <= 1.5 * err['f32'][1], err           # worst element
+        assert err[mode][0] < 5e-8, err
