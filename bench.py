@@ -30,7 +30,7 @@ BASE_KW = dict(model_ksize=2, model_in_blocks=3, model_out_blocks=8, model_chs=7
 # SURVEY.md section 8(d) / BASELINE.md section 3: conv MACs only, 2 FLOP/MAC, unpadded channels
 GFLOP_PER_PATCH = {'base': 268.373, 'upr': 268.437, 'dpp': 277.718}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA; the split kernels spend 6 bf16 MFMA passes per f32 product
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 / f16 MFMA; the split kernels spend 3 (f16x3) or 6 (bf16x6) passes per f32 product
 PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01f_pmc_bs512_base_summary.json')
 
 
@@ -171,14 +171,17 @@ def main():
         secs = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
         flops = sum(f for _, f, _, _ in prof)
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
-        split = engine.CONV_MODE == 'bf16x6'
-        peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split else PEAK_F32_MFMA_TFLOPS
-        kname = 'conv4tap_x6s_kernel<18>' if split else 'conv4tap_kernel<9>'
+        passes = {'f16x3': 3, 'bf16x6': 6}.get(engine.CONV_MODE)
+        split = passes is not None
+        peak = PEAK_BF16_MFMA_TFLOPS / passes if split else PEAK_F32_MFMA_TFLOPS
+        kname = f'conv4tap_x6s_kernel<18, {2 if passes == 3 else 3}>' if split else 'conv4tap_kernel<9>'
+        dtype = {'f16x3': 'f32 (exact 2-way f16 split of power-of-two-scaled operands, 3 MFMA passes, f32 accumulate)',
+                 'bf16x6': 'f32 (exact 3-way bf16 split, 6 MFMA passes, f32 accumulate)'}.get(engine.CONV_MODE, 'f32')
         line = {
             'metric': '96x96 EPI patches/sec fwd+bwd, bs=512', 'value': round(value, 3), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-            'dtype': 'f32 (exact 3-way bf16 split, 6 MFMA passes, f32 accumulate)' if split else 'f32', 'data': 'synthetic',
+            'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.variant.upper()} fwd+bwd+Adam, global bs={args.global_batch} ps={args.patch} '
                                    f'synthetic EPI patches, default torch init (BASELINE.json configs[1])',
                        'per_gpu_batch': B, 'parallelism': f'dp{world}', 'loss': round(loss_val, 6)},
@@ -187,7 +190,7 @@ def main():
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'traffic': pmc_traffic(kname) if args.global_batch == 512 and world == 1 else None,
                          'kernel': kname + ' (280->280 forward + data-gradient launches)',
-                         'peak_is': ('dense bf16 MFMA 2500 TFLOP/s / 6 passes per f32 product' if split
+                         'peak_is': (f'dense 16-bit MFMA 2500 TFLOP/s / {passes} passes per f32 product' if split
                                      else 'f32 MFMA 157.3 TFLOP/s'),
                          'frac_of_f32_mfma_peak': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          'algorithmic_bytes': round(2.0 * B * 98 * 98 * 280 * 4) if args.patch == 96 else None,

@@ -78,7 +78,7 @@ class _Workspace:
 
 # 'f16x3': 2-way f16 split of power-of-two-scaled operands, 3 MFMA passes (f32-equivalent accuracy, 5.3x the
 # f32 MFMA rate); 'bf16x6': 3-way bf16 split, 6 passes (no operand scaling needed); 'f32': exact-f32 MFMA
-CONV_MODE = os.environ.get('MMLF_CONV_MODE', 'bf16x6')
+CONV_MODE = os.environ.get('MMLF_CONV_MODE', 'f16x3')
 
 
 def pack_filter(w, variant, dgrad):
