@@ -14,6 +14,7 @@ def bench(cin, cout, pad, reps=10):
         x.zero_(); w.zero_()
     b = torch.randn(cout, device=dev)
     pk = engine.pack_filter(w, 0, False)
+    x.absmax = x.abs().max().reshape(1)
     out = torch.zeros(geo.alloc * cs_out, device=dev)
     shift, vh, vw = (0, H + 1, W + 1) if pad else (geo.P + 1, H, W)
     for _ in range(2):
@@ -31,12 +32,13 @@ def bench(cin, cout, pad, reps=10):
     g = torch.randn(geo.alloc * cs_out, device=dev)
     gw = torch.zeros(cout, cin, 2, 2, device=dev); gb = torch.zeros(cout, device=dev)
     ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout)), device=dev)
+    x.absmax, g.absmax = x.abs().max().reshape(1), g.abs().max().reshape(1)     # what the producers maintain
     for _ in range(2):
-        call('mmlf_conv2x2_wgrad_split' if engine.CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad', ptr(x), cs_in, cin, ptr(g), cs_out, cout, shift, ptr(gw), ptr(gb), 0, 0, ptr(ws), B, H, W, _lib.stream_ptr())
+        engine.wgrad(geo, x, cs_in, cin, g, cs_out, cout, shift, gw, gb, 0, ws)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        call('mmlf_conv2x2_wgrad_split' if engine.CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad', ptr(x), cs_in, cin, ptr(g), cs_out, cout, shift, ptr(gw), ptr(gb), 0, 0, ptr(ws), B, H, W, _lib.stream_ptr())
+        engine.wgrad(geo, x, cs_in, cin, g, cs_out, cout, shift, gw, gb, 0, ws)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print(f'wgrad {cin}->{cout} pad{pad} B={B}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s algorithmic', flush=True)
