@@ -67,10 +67,10 @@ int mmlf_conv2x2(const float *in, int cs_in, int K, const float *packed, const f
                  float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
                  int B, int H, int W, int relu, const float *relu_ref, int cs_ref, void *stream);
 
-/* Split-precision variant of mmlf_pack_filter / mmlf_conv2x2 (same arguments and semantics).
+/* 3-way bf16 split variant of mmlf_pack_filter / mmlf_conv2x2 (same arguments and semantics; MMLF_CONV_MODE=bf16x6).
  * Every f32 operand is split exactly into three bf16 (hi+mid+lo); each product is evaluated as its six
  * leading cross terms on v_mfma_f32_16x16x32_bf16 with f32 accumulation.  Measured error vs a double
- * reference is at (slightly below) the level of the f32 MFMA fma chain, at 2.67x its rate
+ * reference is at the level of the f32 MFMA fma chain, at 2.67x its rate; needs no operand scaling
  * (DESIGN.md section 4.4).  `packed` holds mmlf_packed_filter_split_bytes(K, N) bytes. */
 int64_t mmlf_packed_filter_split_bytes(int K, int N);
 int mmlf_pack_filter_split(const float *w_oihw, void *packed, int Cout, int Cin, int variant, int dgrad,
