@@ -115,7 +115,16 @@ def _amax_of(t):
     """The device scalar with max |t| that the f16-split kernels scale by.  Grid tensors made by
     Geometry.buf carry it (their producers maintain it); for any other tensor it is computed here."""
     a = getattr(t, 'absmax', None)
-    return a if a is not None else t.abs().max().reshape(1)
+    if a is None:
+        return t.abs().max().reshape(1)
+    if CHECK_ABSMAX:       # test hook: the producers' running maximum must be the tensor's true max |x|
+        true = float(t.abs().max())
+        if float(a) != true:
+            raise AssertionError(f'absmax slot holds {float(a)!r}, tensor max |x| is {true!r}')
+    return a
+
+
+CHECK_ABSMAX = bool(os.environ.get('MMLF_CHECK_ABSMAX'))
 
 
 def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace):
