@@ -92,7 +92,10 @@ int mmlf_pack_filter_h2(const float *w_oihw, void *packed, int Cout, int Cin, in
 int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
                     float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
                     int B, int H, int W, int relu, const float *relu_ref, int cs_ref,
-                    const float *in_amax, float *out_amax, void *stream);
+                    const float *in_amax, float *out_amax,
+                    double *bn_partial /* nullable: see mmlf_bn_stats_finalize */, void *stream);
+/* number of workgroups mmlf_conv2x2_h2 launches for this shape (= rows of bn_partial) */
+int mmlf_conv2x2_blocks(int N, int B, int H, int W);
 
 /* Weight + bias gradient of the convolution above (autograd of feed_forward.py:123,125 reached
  * from train/cli.py:257):  gw[co][ci][tap] (+)= sum_q in[q + off_t][ci] * g[q + g_shift][co],
@@ -130,6 +133,14 @@ int mmlf_bn_coeffs_eval(const float *gamma, const float *beta, const float *runn
  * replaces conv, nn.BatchNorm2d(eval), nn.ReLU (feed_forward.py:125,134-135). */
 int mmlf_fold_bn_eval(const float *w_oihw, const float *bias, const float *scale, const float *shift,
                       float *w_out, float *bias_out, int Cout, int Cin, void *stream);
+/* The second half of mmlf_bn_stats_train for statistics that the convolution already accumulated:
+ * mmlf_conv2x2_h2(bn_partial = partial) writes per-workgroup sums of z and z^2 per channel
+ * ([mmlf_conv2x2_blocks()][2][C] doubles) from its epilogue, so the pad-0 convolution's output is not
+ * read again for nn.BatchNorm2d's training statistics (feed_forward.py:134). */
+int mmlf_bn_stats_finalize(const double *partial, int nblocks, int C, const float *gamma, const float *beta,
+                           float *running_mean, float *running_var, double momentum, double eps,
+                           float *save_mean, float *save_invstd, float *scale, float *shift,
+                           int B, int H, int W, void *stream);
 /* y[q][c_off + c] = interior(q) ? relu(z[q][c]*scale[c] + shift[c]) : 0   (BN apply + nn.ReLU,
  * feed_forward.py:134-135; writing a channel slice implements torch.cat, feed_forward.py:266-267) */
 int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *scale, const float *shift,

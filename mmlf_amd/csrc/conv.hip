@@ -55,6 +55,8 @@ struct ConvArgs {
     const float *in_amax;                // f16 split: max |in| (device scalar) -> power-of-two operand scale
     const float *w_scale;                // f16 split: the scale the packed weights carry (device scalar)
     float *out_amax;                     // optional: running max |out| (device scalar, atomic max)
+    double *bn_partial;                  // optional (f16 split): per-workgroup sums of out and out^2 per channel,
+                                         // [block][2][n_true] doubles, the input of the BatchNorm finalize
 };
 
 // epilogue shared by the f32 and the split-bf16 kernels: D[row = position][col = channel]; a lane
@@ -266,7 +268,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 16x16 tiling: lane (r16, q4) holds column r16 of each 16-column block and rows 16*mb + 4*q4 + r.
 template <int G>
 __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (&acc)[2][G], long long Q0, int w,
-                                                int r16, int q4, float unscale_a, float unscale_w, float &run_max)
+                                                int r16, int q4, float unscale_a, float unscale_w, float &run_max,
+                                                double *stats /* this wave's [16*G][2] sums, or null */)
 {
     const unsigned m = wave_row_mask(a, Q0, w, r16 + 16 * q4) >> (4 * q4);
     const long long qb = Q0 + 32 * w + a.out_shift;                                     // wave-uniform
@@ -284,6 +287,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
         if (ch >= a.n_store) continue;
         const float bvn = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
         unsigned keep = m;
+        float s1 = 0.f, s2 = 0.f;
         if (has_ref) {
             float rv[8];
 #pragma unroll
@@ -301,8 +305,18 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
             if (a.relu) v = fmaxf(v, 0.f);
             v = (keep >> rc & 1) ? v : 0.f;
             run_max = fmaxf(run_max, fabsf(v));
+            s1 += v;
+            s2 = fmaf(v, v, s2);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ob,
                                                   lo + (unsigned)rc * a.cs_out * 4u + 64 * nb, 0, 0);
+        }
+        if (stats) {            // BatchNorm statistics: this wave's 32 positions of channel 16*nb + r16
+            s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+            if (q4 == 0) {      // one owner lane per channel: plain read-modify-write, fixed order
+                stats[2 * (16 * nb + r16)] += (double)s1;
+                stats[2 * (16 * nb + r16) + 1] += (double)s2;
+            }
         }
     }
 }
@@ -419,6 +433,10 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     int tile = first_tile, c = 0;          // chunk being multiplied
     int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
     if (tile >= ntiles) return;
+    // optional BatchNorm statistics of the output: per-wave double sums behind the two pipeline buffers
+    double *stats_all = reinterpret_cast<double *>(lds + 2 * BUF_F4);        // [8 waves][NP][2]
+    if (a.bn_partial)
+        for (int k = tid; k < 8 * NP * 2; k += 512) stats_all[k] = 0.0;      // ordered by the barrier below
     // f16 split: operand scales (powers of two) and what undoes them in the epilogue
     float scale_a = 1.f, unscale_a = 1.f, unscale_w = 1.f, run_max = 0.f;
     if constexpr (PL == 2) {
@@ -521,7 +539,8 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
         // BEFORE the epilogue, so that its stores (same counter) stay in flight across the barrier
         X6_DMA_WAIT();
         if (++c == a.nchunk) {
-            conv_epilogue16<G>(a, acc, (long long)tile * MMLF_TILE, w, r16, q4, unscale_a, unscale_w, run_max);
+            conv_epilogue16<G>(a, acc, (long long)tile * MMLF_TILE, w, r16, q4, unscale_a, unscale_w, run_max,
+                               a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -535,6 +554,15 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
         buf ^= 1;
     }
     if (a.out_amax) mmlf_amax_update(run_max, a.out_amax);      // at most one atomic per wave per launch
+    if (a.bn_partial) {                                         // the loop's last barrier ordered the wave sums
+        for (int k = tid; k < 2 * a.n_true; k += 512) {
+            const int ch = k % a.n_true, which = k / a.n_true;
+            double t = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) t += stats_all[((size_t)ww * NP + ch) * 2 + which];
+            a.bn_partial[((size_t)blockIdx.x * 2 + which) * a.n_true + ch] = t;
+        }
+    }
 #undef X6_DMA_PIECE
 #undef X6_DMA_SLOT
 #undef X6_DMA_WAIT
@@ -1513,18 +1541,25 @@ static int device_cus()
 }
 
 // persistent launches: one workgroup per CU (two for the narrow variants), each walks tiles b, b+grid, ...
+static long long conv_split_blocks(int G, long long ntiles)
+{
+    const long long grid = (G <= 6 ? 2ll : 1ll) * device_cus();
+    return grid > ntiles ? ntiles : grid;
+}
+
 template <int G, int PL>
 static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
-    constexpr size_t lds = 2 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
+    constexpr size_t lds_pipe = 2 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
+    constexpr size_t lds_stats = 8 * (G * 16) * 2 * sizeof(double);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_pipe + (PL == 2 ? lds_stats : 0)));
         attr_done = true;
     }
-    long long grid = (G <= 6 ? 2ll : 1ll) * device_cus();
-    if (grid > ntiles) grid = ntiles;
+    const size_t lds = lds_pipe + (a.bn_partial ? lds_stats : 0);
+    const long long grid = conv_split_blocks(G, ntiles);
     hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL>), dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
     return mmlf_launch_status(PL == 3 ? "mmlf_conv2x2_split" : "mmlf_conv2x2_h2");
 }
@@ -1545,7 +1580,7 @@ static int launch_conv_split(int np, const ConvArgs &a, long long ntiles, hipStr
 static int conv_split_impl(const char *who, int planes, const float *in, int cs_in, int K, const void *packed,
                            const float *bias, int N, float *out, int cs_out, int N_store, int out_shift, int vh,
                            int vw, int B, int H, int W, int relu, const float *relu_ref, int cs_ref,
-                           const float *in_amax, float *out_amax, void *stream)
+                           const float *in_amax, float *out_amax, double *bn_partial, void *stream)
 {
     MMLF_CHECK_ARG(in && packed && out, "%s: null pointer", who);
     MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0, "%s: bad shape B=%d H=%d W=%d", who, B, H, W);
@@ -1564,7 +1599,8 @@ static int conv_split_impl(const char *who, int planes, const float *in, int cs_
     a.in = in; a.wp = reinterpret_cast<const float *>(packed); a.bias = bias; a.out = out; a.ref = relu_ref;
     a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
     a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
-    a.in_amax = in_amax; a.out_amax = out_amax;
+    a.in_amax = in_amax; a.out_amax = out_amax; a.bn_partial = bn_partial;
+    MMLF_CHECK_ARG(!bn_partial || (planes == 2 && N_store >= N), "%s: BatchNorm statistics need the f16 split path", who);
     // the f16-packed filter ends with the scale it carries
     a.w_scale = planes == 2 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed) +
                                                                 (size_t)(cs_in / 8) * 8 * np * 16)
@@ -1584,7 +1620,7 @@ extern "C" int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void 
                                   int W, int relu, const float *relu_ref, int cs_ref, void *stream)
 {
     return conv_split_impl("mmlf_conv2x2_split", 3, in, cs_in, K, packed, bias, N, out, cs_out, N_store, out_shift,
-                           vh, vw, B, H, W, relu, relu_ref, cs_ref, nullptr, nullptr, stream);
+                           vh, vw, B, H, W, relu, relu_ref, cs_ref, nullptr, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------ f16 2-way split ("f16x3") entry points
@@ -1622,8 +1658,16 @@ extern "C" int mmlf_pack_filter_h2(const float *w, void *packed, int Cout, int C
 extern "C" int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
                                float *out, int cs_out, int N_store, int out_shift, int vh, int vw, int B, int H,
                                int W, int relu, const float *relu_ref, int cs_ref, const float *in_amax,
-                               float *out_amax, void *stream)
+                               float *out_amax, double *bn_partial, void *stream)
 {
     return conv_split_impl("mmlf_conv2x2_h2", 2, in, cs_in, K, packed, bias, N, out, cs_out, N_store, out_shift, vh,
-                           vw, B, H, W, relu, relu_ref, cs_ref, in_amax, out_amax, stream);
+                           vw, B, H, W, relu, relu_ref, cs_ref, in_amax, out_amax, bn_partial, stream);
+}
+
+extern "C" int mmlf_conv2x2_blocks(int N, int B, int H, int W)
+{
+    const int np = x6_np(N);
+    if (np < 0 || B <= 0 || H <= 0 || W <= 0) return -1;
+    const Grid g = make_grid(B, H, W);
+    return (int)conv_split_blocks(np / 16, g.NQpad / MMLF_TILE);
 }

@@ -809,6 +809,19 @@ extern "C" int mmlf_bn_stats_train(const float *z, int cs, int C, const float *g
     return mmlf_launch_status("mmlf_bn_stats_train");
 }
 
+extern "C" int mmlf_bn_stats_finalize(const double *partial, int nblocks, int C, const float *gamma,
+                                      const float *beta, float *running_mean, float *running_var, double momentum,
+                                      double eps, float *save_mean, float *save_invstd, float *scale, float *shift,
+                                      int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(partial && save_mean && save_invstd && scale && shift && C > 0 && nblocks > 0,
+                   "mmlf_bn_stats_finalize: bad argument");
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, nblocks, C,
+                       (double)B * H * W, gamma, beta, running_mean, running_var, momentum, eps, save_mean,
+                       save_invstd, scale, shift);
+    return mmlf_launch_status("mmlf_bn_stats_finalize");
+}
+
 extern "C" int mmlf_bn_coeffs_eval(const float *gamma, const float *beta, const float *rm, const float *rv,
                                    double eps, float *scale, float *shift, int C, void *stream)
 {

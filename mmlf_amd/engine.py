@@ -139,7 +139,9 @@ def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace
 
 
 def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0,
-         n_store=None, out_off=0):
+         n_store=None, out_off=0, bn_partial=None):
+    """bn_partial (f16x3 only): a float64 buffer that receives per-workgroup sums of the output and its
+    square per channel -- BatchNorm's training statistics without another pass over the output."""
     prof = PROFILE is not None and K >= 256 and N >= 256
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -148,7 +150,7 @@ def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu
             cs_out if n_store is None else n_store, out_shift, vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref)
     if CONV_MODE == 'f16x3':
         ax = _amax_of(x)
-        call('mmlf_conv2x2_h2', *args, ptr(ax), ptr(getattr(out, 'absmax', None)), _lib.stream_ptr())
+        call('mmlf_conv2x2_h2', *args, ptr(ax), ptr(getattr(out, 'absmax', None)), ptr(bn_partial), _lib.stream_ptr())
     else:
         call('mmlf_conv2x2_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2', *args, _lib.stream_ptr())
     if prof:
@@ -215,7 +217,9 @@ class Trunk:
             return out, cs_out
         pk2 = pack_filter(w2, var, False)
         z = geo.buf(cs_mid, dev)
-        conv(geo, y, cs_mid, cmid, pk2, b2, cmid, z, cs_mid, P + 1, H, W, False)
+        fused_stats = spec.bn and train and CONV_MODE == 'f16x3'      # statistics from the conv epilogue
+        conv(geo, y, cs_mid, cmid, pk2, b2, cmid, z, cs_mid, P + 1, H, W, False,
+             bn_partial=ws.partial if fused_stats else None)
         rec = {'spec': spec, 'var': var, 'x': x, 'cs_x': cs_x, 'y': y, 'z': z}
         if not spec.bn:
             if rec_list is not None:
@@ -227,9 +231,15 @@ class Trunk:
         g, bt = p[f'{spec.prefix}.3.weight'], p[f'{spec.prefix}.3.bias']
         rm, rv = p[f'{spec.prefix}.3.running_mean'], p[f'{spec.prefix}.3.running_var']
         if train:
-            call('mmlf_bn_stats_train', ptr(z), cs_mid, C, ptr(g), ptr(bt), ptr(rm), ptr(rv), self.momentum,
-                 self.eps, ptr(smean), ptr(sinv), ptr(scale), ptr(shift), ptr(ws.partial), BN_BLOCKS, B, H, W,
-                 _lib.stream_ptr())
+            if fused_stats:
+                nblk = int(_lib.load().mmlf_conv2x2_blocks(cmid, B, H, W))
+                call('mmlf_bn_stats_finalize', ptr(ws.partial), nblk, C, ptr(g), ptr(bt), ptr(rm), ptr(rv),
+                     self.momentum, self.eps, ptr(smean), ptr(sinv), ptr(scale), ptr(shift), B, H, W,
+                     _lib.stream_ptr())
+            else:
+                call('mmlf_bn_stats_train', ptr(z), cs_mid, C, ptr(g), ptr(bt), ptr(rm), ptr(rv), self.momentum,
+                     self.eps, ptr(smean), ptr(sinv), ptr(scale), ptr(shift), ptr(ws.partial), BN_BLOCKS, B, H, W,
+                     _lib.stream_ptr())
             p[f'{spec.prefix}.3.num_batches_tracked'].add_(1)
         else:
             call('mmlf_bn_coeffs_eval', ptr(g), ptr(bt), ptr(rm), ptr(rv), self.eps, ptr(scale), ptr(shift), C,
