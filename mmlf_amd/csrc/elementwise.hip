@@ -30,6 +30,19 @@ template <> struct VecIO<4> {
     {
         *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
     }
+    // streamed once: keep it out of the way of data that is re-read
+    static __device__ __forceinline__ void load_nt(const float *p, float *o)
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+    }
+    static __device__ __forceinline__ void store_nt(float *p, const float *o)
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+    }
 };
 template <> struct VecIO<2> {
     static __device__ __forceinline__ void load(const float *p, float *o)
@@ -41,6 +54,8 @@ template <> struct VecIO<2> {
     {
         *reinterpret_cast<float2 *>(p) = make_float2(o[0], o[1]);
     }
+    static __device__ __forceinline__ void load_nt(const float *p, float *o) { load(p, o); }
+    static __device__ __forceinline__ void store_nt(float *p, const float *o) { store(p, o); }
 };
 
 // V = channels per thread access (4 when every slice start is 16-byte aligned, else 2: the
@@ -77,13 +92,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
         const size_t base = ((size_t)(b * R + y) * P + 1);  // first interior position of the row
         for (int x = pl; active && x < W; x += ppi) {
             float zz[V];
-            VecIO<V>::load(z + (base + x) * cs_z + V * cg, zz);
+            VecIO<V>::load_nt(z + (base + x) * cs_z + V * cg, zz);
             if (!BWD) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) { s0[e] += zz[e]; s1[e] += (double)zz[e] * zz[e]; }
             } else {
                 float gg[V];
-                VecIO<V>::load(gy + (base + x) * cs_gy + c_off + V * cg, gg);
+                VecIO<V>::load_nt(gy + (base + x) * cs_gy + c_off + V * cg, gg);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     const float u = fmaf(zz[e], sc[e], sh[e]);
@@ -245,8 +260,8 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
         for (int k = 0; k < V; ++k) o[k] = 0.f;
         if (row_in && x >= 1 && x <= W && V * cg < C) {
             float zz[V], gg[V];
-            VecIO<V>::load(z + (base + x) * cs_z + V * cg, zz);
-            if (MODE == 1) VecIO<V>::load(gy + (base + x) * cs_gy + c_off_gy + V * cg, gg);
+            VecIO<V>::load_nt(z + (base + x) * cs_z + V * cg, zz);
+            if (MODE == 1) VecIO<V>::load_nt(gy + (base + x) * cs_gy + c_off_gy + V * cg, gg);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const int c = V * cg + k;      // channels >= C have zero coefficients -> output 0
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
         for (int k = 0; k < V; ++k) mx = fmaxf(mx, fabsf(o[k]));
         float *op = out + (base + x) * cs_out + c_off_out + V * cg;
         if (V * cg + V - 1 < C_store) {
-            VecIO<V>::store(op, o);
+            VecIO<V>::store_nt(op, o);
         } else {
 #pragma unroll
             for (int k = 0; k < V; ++k)
