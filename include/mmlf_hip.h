@@ -88,7 +88,10 @@ int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void *packed, co
  * max(*out_amax, max |out|) by atomic max -- zero it before the first producer of a tensor.
  * `packed` holds mmlf_packed_filter_h2_bytes(K, N) bytes (the weights' own scale is stored behind them). */
 int64_t mmlf_packed_filter_h2_bytes(int K, int N);
-int mmlf_pack_filter_h2(const float *w_oihw, void *packed, int Cout, int Cin, int variant, int dgrad, void *stream);
+int mmlf_pack_filter_h2(const float *w_oihw, void *packed, int Cout, int Cin, int variant, int dgrad,
+                        const float *w_amax /* nullable: device scalar max |w|, else computed here */, void *stream);
+/* max |x| of n float tensors in one launch: ptrs / sizes are DEVICE arrays (const float*[n], int64[n]) */
+int mmlf_amax_many(const void *ptrs, const void *sizes, int n, float *out, void *stream);
 int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
                     float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
                     int B, int H, int W, int relu, const float *relu_ref, int cs_ref,

@@ -1631,8 +1631,31 @@ extern "C" int64_t mmlf_packed_filter_h2_bytes(int K, int N)
     return (int64_t)((K + 7) / 8) * 8 * np * 16 + 16;      // + the scale the packed weights carry
 }
 
+// max |x| of n tensors in one launch: block b reduces tensor b
+__global__ __launch_bounds__(256) void amax_many_kernel(const float *const *__restrict__ ptrs,
+                                                        const long long *__restrict__ sizes, float *__restrict__ out)
+{
+    const float *x = ptrs[blockIdx.x];
+    const long long n = sizes[blockIdx.x];
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+    __shared__ float red[4];
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+extern "C" int mmlf_amax_many(const void *ptrs, const void *sizes, int n, float *out, void *stream)
+{
+    MMLF_CHECK_ARG(ptrs && sizes && out && n > 0, "mmlf_amax_many: bad argument");
+    hipLaunchKernelGGL(amax_many_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float *const *>(ptrs), reinterpret_cast<const long long *>(sizes), out);
+    return mmlf_launch_status("mmlf_amax_many");
+}
+
 extern "C" int mmlf_pack_filter_h2(const float *w, void *packed, int Cout, int Cin, int variant, int dgrad,
-                                   void *stream)
+                                   const float *w_amax, void *stream)
 {
     MMLF_CHECK_ARG(w && packed, "mmlf_pack_filter_h2: null pointer");
     MMLF_CHECK_ARG(variant >= 0 && variant <= 2, "mmlf_pack_filter_h2: bad variant %d", variant);
@@ -1642,16 +1665,19 @@ extern "C" int mmlf_pack_filter_h2(const float *w, void *packed, int Cout, int C
     const int nchunk = (K + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     float *tail = reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + (size_t)nchunk * 8 * NP * 16);
-    // tail[0] = scale, tail[1] = max |w| (scratch)
-    if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return mmlf_fail("mmlf_pack_filter_h2: memset failed");
-    const long long nw = (long long)Cout * Cin * 4;
-    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((nw + 1023) / 1024 > 256 ? 256 : (nw + 1023) / 1024)), dim3(256),
-                       0, st, w, nw, tail + 1);
+    // tail[0] = scale; without a caller-supplied max |w|: tail[1] = max |w| (scratch), computed here
+    if (!w_amax) {
+        if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return mmlf_fail("mmlf_pack_filter_h2: memset failed");
+        const long long nw = (long long)Cout * Cin * 4;
+        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((nw + 1023) / 1024 > 256 ? 256 : (nw + 1023) / 1024)),
+                           dim3(256), 0, st, w, nw, tail + 1);
+        w_amax = tail + 1;
+    }
     const long long total = (long long)nchunk * 32 * NP;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_filter_h2_kernel, dim3(blocks), dim3(256), 0, st, w, (unsigned short *)packed, Cout, Cin,
-                       variant, dgrad, nchunk, NP, tail + 1, tail);
+                       variant, dgrad, nchunk, NP, w_amax, tail);
     return mmlf_launch_status("mmlf_pack_filter_h2");
 }
 

@@ -81,7 +81,8 @@ class _Workspace:
 CONV_MODE = os.environ.get('MMLF_CONV_MODE', 'f16x3')
 
 
-def pack_filter(w, variant, dgrad):
+def pack_filter(w, variant, dgrad, w_amax=None):
+    """w_amax (f16x3): device scalar max |w|; computed by the pack call when absent."""
     cout, cin = w.shape[0], w.shape[1]
     K, N = (cout, cin) if dgrad else (cin, cout)
     if CONV_MODE == 'f16x3':
@@ -89,7 +90,7 @@ def pack_filter(w, variant, dgrad):
         if n < 0:
             raise RuntimeError(f'pack_filter: unsupported channels K={K} N={N}')
         out = torch.empty(n // 4, dtype=torch.float32, device=w.device)
-        call('mmlf_pack_filter_h2', ptr(w), ptr(out), cout, cin, variant, int(dgrad), _lib.stream_ptr())
+        call('mmlf_pack_filter_h2', ptr(w), ptr(out), cout, cin, variant, int(dgrad), ptr(w_amax), _lib.stream_ptr())
         return out
     if CONV_MODE == 'bf16x6':
         n = int(_lib.load().mmlf_packed_filter_split_bytes(cs_of(K), N))
@@ -170,6 +171,7 @@ class Trunk:
 
     def __init__(self, chs, in_blocks, out_blocks, views, oc, momentum, eps=1e-5):
         self.chs, self.views, self.oc = chs, views, oc
+        self._wabs, self._wtab = {}, None
         self.momentum, self.eps = float(momentum), float(eps)
         cin0 = views * 3
         self.streams = []
@@ -184,6 +186,29 @@ class Trunk:
         if chs % 2 or cs_of(c) != c:
             raise ValueError('native trunk needs an even model_chs with 4*model_chs a multiple of 8')
 
+    # ------------------------------------------------------------------ weights' max |w| (f16x3 scales)
+    def _weight_absmax(self, p):
+        """max |w| of every conv weight in ONE launch (device pointer table cached per parameter set)."""
+        if CONV_MODE != 'f16x3':
+            return {}
+        names = []
+        for _, _, blocks in self.streams:
+            for spec in blocks:
+                names += [f'{spec.prefix}.0.weight', f'{spec.prefix}.2.weight']
+        for spec in self.out_blocks:
+            names += [f'{spec.prefix}.0.weight', f'{spec.prefix}.2.weight']
+        names = list(dict.fromkeys(names))
+        key = tuple(p[n].data_ptr() for n in names)
+        cache = getattr(self, '_wtab', None)
+        if cache is None or cache[0] != key:
+            dev = p[names[0]].device
+            ptrs = torch.tensor(list(key), dtype=torch.int64).to(dev)
+            sizes = torch.tensor([p[n].numel() for n in names], dtype=torch.int64).to(dev)
+            cache = self._wtab = (key, ptrs, sizes)
+        out = torch.empty(len(names), dtype=torch.float32, device=cache[1].device)
+        call('mmlf_amax_many', ptr(cache[1]), ptr(cache[2]), len(names), ptr(out), _lib.stream_ptr())
+        return {n: out[k:k + 1] for k, n in enumerate(names)}
+
     # ------------------------------------------------------------------ forward
     def _block_fwd(self, geo, spec, var, x, cs_x, p, train, rec_list, out=None, cs_out=None, c_off=0):
         """x: grid tensor (extent H,W at (1,1)).  Returns the block output grid tensor."""
@@ -193,7 +218,7 @@ class Trunk:
         cmid, cs_mid = spec.cout, cs_of(spec.cout)
         w1, b1 = p[f'{spec.prefix}.0.weight'], p[f'{spec.prefix}.0.bias']
         w2, b2 = p[f'{spec.prefix}.2.weight'], p[f'{spec.prefix}.2.bias']
-        pk1 = pack_filter(w1, var, False)
+        pk1 = pack_filter(w1, var, False, self._wabs.get(f'{spec.prefix}.0.weight'))
         y = geo.buf(cs_mid, dev)
         conv(geo, x, cs_x, spec.cin, pk1, b1, cmid, y, cs_mid, 0, H + 1, W + 1, True)
         if spec.bn and not train and rec_list is None:   # rec_list is None when nothing is saved for backward
@@ -215,7 +240,7 @@ class Trunk:
                 n_store = C
             conv(geo, y, cs_mid, cmid, pk2, b2f, cmid, out, cs_out, P + 1, H, W, True, n_store=n_store, out_off=c_off)
             return out, cs_out
-        pk2 = pack_filter(w2, var, False)
+        pk2 = pack_filter(w2, var, False, self._wabs.get(f'{spec.prefix}.2.weight'))
         z = geo.buf(cs_mid, dev)
         fused_stats = spec.bn and train and CONV_MODE == 'f16x3'      # statistics from the conv epilogue
         conv(geo, y, cs_mid, cmid, pk2, b2, cmid, z, cs_mid, P + 1, H, W, False,
@@ -265,6 +290,7 @@ class Trunk:
         dev = h.device
         geo = Geometry(B, H, W)
         cin0 = n * c
+        self._wabs = self._weight_absmax(p)
         tape = {'geo': geo, 'streams': [], 'out': []}
         concat = geo.buf(4 * self.chs, dev)
         for s, (key, var, blocks) in enumerate(self.streams):
@@ -314,7 +340,7 @@ class Trunk:
         # conv2 (pad 0): weight/bias gradient, then data gradient fused with the ReLU mask of y
         wgrad(geo, y, cs_mid, C, dz, cs_mid, C, P + 1, grads[f'{pre}.2.weight'], grads[f'{pre}.2.bias'], var,
               ws.wgrad_ws(C, C))
-        pk = pack_filter(w2, var, True)
+        pk = pack_filter(w2, var, True, self._wabs.get(f'{pre}.2.weight'))
         dy = geo.buf(cs_mid, dev)
         conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
         del dz
@@ -323,7 +349,7 @@ class Trunk:
               ws.wgrad_ws(spec.cin, C))
         if not need_dx:
             return None
-        pk = pack_filter(w1, var, True)
+        pk = pack_filter(w1, var, True, self._wabs.get(f'{pre}.0.weight'))
         dx = geo.buf(cs_x, dev)
         conv(geo, dy, cs_mid, C, pk, None, spec.cin, dx, cs_x, P + 1, H, W, False)
         return dx
@@ -333,6 +359,7 @@ class Trunk:
         (the caller zeroes them).  on_done(key) is called when every gradient of 'out_net.k' /
         'in_net_id' / 'in_net_hv' has been enqueued (gradient-bucket all-reduce hook)."""
         geo = tape['geo']
+        self._wabs = self._weight_absmax(p)
         dev = grad_output.device
         B, H, W = geo.B, geo.H, geo.W
         cs = cs_of(self.oc)
