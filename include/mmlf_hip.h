@@ -167,6 +167,8 @@ int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const float *z, int
 int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int B, int H, int W,
                    float *amax_out /* nullable: atomic max |x| */, void *stream);
 int mmlf_unpack_nchw(const float *grid, int cs, float *nchw, int C, int B, int H, int W, void *stream);
+/* zero the slack of a freshly allocated grid buffer: positions [0, P+1) and [B*G, mmlf_grid_alloc_positions) */
+int mmlf_zero_slack(float *grid, int cs, int B, int H, int W, void *stream);
 
 /* UPR head (feed_forward.py:292-302, laplacian :9-12): posterior[b,k,y,x] from output[:,0:2]. */
 int mmlf_head_upr(const float *output_nchw, const float *grid108, float *posterior, int steps,

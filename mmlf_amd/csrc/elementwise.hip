@@ -921,6 +921,25 @@ extern "C" int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int
     return mmlf_launch_status("mmlf_pack_nchw");
 }
 
+// zero the head and tail slack of a grid buffer in one launch
+__global__ void zero_slack_kernel(float *__restrict__ buf, long long head, long long tail_off, long long tail)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < head + tail;
+         i += (long long)gridDim.x * blockDim.x)
+        buf[i < head ? i : tail_off + (i - head)] = 0.f;
+}
+
+extern "C" int mmlf_zero_slack(float *grid, int cs, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(grid && cs > 0 && B > 0 && H > 0 && W > 0, "mmlf_zero_slack: bad argument");
+    const Grid g = make_grid(B, H, W);
+    const long long head = (long long)(g.P + 1) * cs, tail_off = g.NQ * cs;
+    const long long tail = (grid_alloc_positions(g) - g.NQ) * cs;
+    hipLaunchKernelGGL(zero_slack_kernel, dim3(ew_blocks(head + tail)), dim3(256), 0, (hipStream_t)stream, grid, head,
+                       tail_off, tail);
+    return mmlf_launch_status("mmlf_zero_slack");
+}
+
 extern "C" int mmlf_unpack_nchw(const float *grid, int cs, float *nchw, int C, int B, int H, int W, void *stream)
 {
     MMLF_CHECK_ARG(nchw && grid && C > 0 && C <= cs, "mmlf_unpack_nchw: C=%d cs=%d", C, cs);

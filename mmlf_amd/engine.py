@@ -44,8 +44,7 @@ class Geometry:
     def buf(self, cs, device):
         """Grid buffer with zeroed head/tail slack (the kernels write everything else)."""
         t = torch.empty(self.alloc * cs, dtype=torch.float32, device=device)
-        t[:(self.P + 1) * cs].zero_()
-        t[self.NQ * cs:].zero_()
+        call('mmlf_zero_slack', ptr(t), cs, self.B, self.H, self.W, _lib.stream_ptr())
         t.absmax = self._amax_slot(device)
         return t
 
