@@ -1631,26 +1631,24 @@ extern "C" int64_t mmlf_packed_filter_h2_bytes(int K, int N)
     return (int64_t)((K + 7) / 8) * 8 * np * 16 + 16;      // + the scale the packed weights carry
 }
 
-// max |x| of n tensors in one launch: block b reduces tensor b
+// max |x| of n tensors in one launch: blocks (b, 0..15) reduce sixteenths of tensor b (out zeroed first)
 __global__ __launch_bounds__(256) void amax_many_kernel(const float *const *__restrict__ ptrs,
                                                         const long long *__restrict__ sizes, float *__restrict__ out)
 {
     const float *x = ptrs[blockIdx.x];
     const long long n = sizes[blockIdx.x];
     float m = 0.f;
-    for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
-    __shared__ float red[4];
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (long long i = blockIdx.y * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.y) m = fmaxf(m, fabsf(x[i]));
+    mmlf_amax_update(m, out + blockIdx.x);
 }
 
 extern "C" int mmlf_amax_many(const void *ptrs, const void *sizes, int n, float *out, void *stream)
 {
     MMLF_CHECK_ARG(ptrs && sizes && out && n > 0, "mmlf_amax_many: bad argument");
-    hipLaunchKernelGGL(amax_many_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float *const *>(ptrs), reinterpret_cast<const long long *>(sizes), out);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st) != hipSuccess) return mmlf_fail("mmlf_amax_many: memset failed");
+    hipLaunchKernelGGL(amax_many_kernel, dim3(n, 16), dim3(256), 0, st, reinterpret_cast<const float *const *>(ptrs),
+                       reinterpret_cast<const long long *>(sizes), out);
     return mmlf_launch_status("mmlf_amax_many");
 }
 
