@@ -64,15 +64,18 @@ class _Workspace:
     def __init__(self, device):
         self.device = device
         self.wgrad = None
+        self.wgrad_side = None                       # workspace of weight-gradient launches on the side stream
+        self.side = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
         self.partial = torch.empty(2 * 512 * max(BN_BLOCKS, LOSS_BLOCKS) + 8, dtype=torch.float64, device=device)
 
-    def wgrad_ws(self, cin, cout):
+    def wgrad_ws(self, cin, cout, side=False):
         n = int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout))
         if n < 0:
             raise RuntimeError(f'wgrad: unsupported channels {cin}->{cout}')
-        if self.wgrad is None or self.wgrad.numel() < n:
-            self.wgrad = torch.empty(n, dtype=torch.float32, device=self.device)
-        return self.wgrad
+        name = 'wgrad_side' if side else 'wgrad'
+        if getattr(self, name) is None or getattr(self, name).numel() < n:
+            setattr(self, name, torch.empty(n, dtype=torch.float32, device=self.device))
+        return getattr(self, name)
 
 
 # 'f16x3': 2-way f16 split of power-of-two-scaled operands, 3 MFMA passes (f32-equivalent accuracy, 5.3x the
@@ -125,6 +128,8 @@ def _amax_of(t):
 
 
 CHECK_ABSMAX = bool(os.environ.get('MMLF_CHECK_ABSMAX'))
+# run conv1's weight gradient of the wide blocks on a side stream beside the next BatchNorm-backward kernels
+OVERLAP_WGRAD = os.environ.get('MMLF_OVERLAP_WGRAD', '1') != '0'
 
 
 def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace):
@@ -314,8 +319,12 @@ class Trunk:
         return out, (tape if save else None)
 
     # ------------------------------------------------------------------ backward
-    def _block_bwd(self, geo, rec, p, grads, gy, cs_gy, c_off, need_dx, dx_out=None, cs_dx=None):
-        """gy: gradient w.r.t. the block output (grid, extent (H,W)).  Returns dX grid tensor."""
+    def _block_bwd(self, geo, rec, p, grads, gy, cs_gy, c_off, need_dx, after_bn=None, overlap=False):
+        """gy: gradient w.r.t. the block output (grid, extent (H,W)).  Returns dX grid tensor.
+        after_bn: called once this block's BatchNorm-backward kernels are enqueued.  overlap: run the
+        first convolution's weight gradient on the side stream AFTER the data gradient is enqueued, so that
+        it (matrix-core bound) runs beside the BatchNorm-backward kernels of the block underneath (HBM
+        bound), which only need the data gradient; returns (dX, event) then."""
         spec, var = rec['spec'], rec['var']
         dev = gy.device
         ws = _Workspace.get(dev)
@@ -335,6 +344,8 @@ class Trunk:
         else:
             assert c_off == 0 and cs_gy == cs_mid
             dz = gy
+        if after_bn:
+            after_bn()
         w1, w2 = p[f'{pre}.0.weight'], p[f'{pre}.2.weight']
         # conv2 (pad 0): weight/bias gradient, then data gradient fused with the ReLU mask of y
         wgrad(geo, y, cs_mid, C, dz, cs_mid, C, P + 1, grads[f'{pre}.2.weight'], grads[f'{pre}.2.bias'], var,
@@ -344,6 +355,20 @@ class Trunk:
         conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
         del dz
         # conv1 (pad 1)
+        if overlap and need_dx:
+            pk = pack_filter(w1, var, True, self._wabs.get(f'{pre}.0.weight'))
+            dx = geo.buf(cs_x, dev)
+            conv(geo, dy, cs_mid, C, pk, None, spec.cin, dx, cs_x, P + 1, H, W, False)
+            main = torch.cuda.current_stream()
+            ready = main.record_event()
+            with torch.cuda.stream(ws.side):
+                ws.side.wait_event(ready)
+                wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'],
+                      var, ws.wgrad_ws(spec.cin, C, side=True))
+                done = ws.side.record_event()
+            x.record_stream(ws.side)        # both are freed by the caller while the side stream may still read them
+            dy.record_stream(ws.side)
+            return dx, done
         wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'], var,
               ws.wgrad_ws(spec.cin, C))
         if not need_dx:
@@ -367,15 +392,35 @@ class Trunk:
              _lib.stream_ptr())
         cs_g = cs
         recs = tape['out']
+        main = torch.cuda.current_stream()
+        pending = None                      # (event, prefix) of a weight gradient still running on the side stream
+
+        def settle():
+            nonlocal pending
+            if pending is not None:
+                main.wait_event(pending[0])
+                if on_done:
+                    on_done(pending[1])
+                pending = None
+
         while recs:
             rec = recs.pop()
-            g = self._block_bwd(geo, rec, p, grads, g, cs_g, 0, True)
+            wide = OVERLAP_WGRAD and rec['spec'].cin >= 128
+            res = self._block_bwd(geo, rec, p, grads, g, cs_g, 0, True, after_bn=settle, overlap=wide)
+            settle()                        # (blocks without BatchNorm never called it)
+            if wide:
+                g, ev = res
+                pending = (ev, rec['spec'].prefix)
+            else:
+                g = res
+                if on_done:
+                    on_done(rec['spec'].prefix)
             cs_g = rec['cs_x']
-            if on_done:
-                on_done(rec['spec'].prefix)
         # g is now the gradient w.r.t. the concat buffer (cs = 4*chs); streams read channel slices
         for s in reversed(range(4)):
             recs = tape['streams'][s]
+            if s == 2:
+                settle()                    # out_net.0's weight gradient ran beside the first stream's BatchNorm kernels
             gs, cs_s, off = g, cs_g, s * self.chs
             while recs:
                 rec = recs.pop()
