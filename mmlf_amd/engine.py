@@ -324,7 +324,7 @@ class Trunk:
         after_bn: called once this block's BatchNorm-backward kernels are enqueued.  overlap: run the
         first convolution's weight gradient on the side stream AFTER the data gradient is enqueued, so that
         it (matrix-core bound) runs beside the BatchNorm-backward kernels of the block underneath (HBM
-        bound), which only need the data gradient; returns (dX, event) then."""
+        bound), which only need the data gradient; returns (dX, event, tensors to keep alive until the event) then."""
         spec, var = rec['spec'], rec['var']
         dev = gy.device
         ws = _Workspace.get(dev)
@@ -366,9 +366,9 @@ class Trunk:
                 wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'],
                       var, ws.wgrad_ws(spec.cin, C, side=True))
                 done = ws.side.record_event()
-            x.record_stream(ws.side)        # both are freed by the caller while the side stream may still read them
-            dy.record_stream(ws.side)
-            return dx, done
+            # x and dy are read by the side stream: the caller keeps them alive until the main stream has waited
+            # for `done` (no record_stream: deferred reuse makes the caching allocator grow and stall)
+            return dx, done, (x, dy)
         wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'], var,
               ws.wgrad_ws(spec.cin, C))
         if not need_dx:
@@ -401,7 +401,7 @@ class Trunk:
                 main.wait_event(pending[0])
                 if on_done:
                     on_done(pending[1])
-                pending = None
+                pending = None              # drops the tensors the side stream was reading
 
         while recs:
             rec = recs.pop()
@@ -409,8 +409,8 @@ class Trunk:
             res = self._block_bwd(geo, rec, p, grads, g, cs_g, 0, True, after_bn=settle, overlap=wide)
             settle()                        # (blocks without BatchNorm never called it)
             if wide:
-                g, ev = res
-                pending = (ev, rec['spec'].prefix)
+                g, ev, keep = res
+                pending = (ev, rec['spec'].prefix, keep)
             else:
                 g = res
                 if on_done:
