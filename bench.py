@@ -31,7 +31,7 @@ BASE_KW = dict(model_ksize=2, model_in_blocks=3, model_out_blocks=8, model_chs=7
 GFLOP_PER_PATCH = {'base': 268.373, 'upr': 268.437, 'dpp': 277.718}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 / f16 MFMA; the split kernels spend 3 (f16x3) or 6 (bf16x6) passes per f32 product
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01h_pmc_bs512_base_summary.json')
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01i_pmc_bs512_base_summary.json')
 
 
 def pmc_traffic(kernel):
