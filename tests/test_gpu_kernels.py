@@ -363,3 +363,65 @@ def test_split_arithmetic_is_at_f32_accuracy():
         assert err[mode][0] <= 1.1 * err['f32'][0], err           # mean error relative to sum|a*b|
         assert err[mode][1] <= 1.5 * err['f32'][1], err           # worst element
         assert err[mode][0] < 5e-8, err
+
+
+@pytest.mark.parametrize('cin,cout', [(280, 280), (70, 70)])
+def test_fused_batchnorm_statistics_match_the_two_pass_form(cin, cout):
+    """The f16-split convolution accumulates BatchNorm's training statistics of its output in the epilogue
+    (mmlf_conv2x2_h2(bn_partial) + mmlf_bn_stats_finalize); they must equal mmlf_bn_stats_train run on the
+    stored output, including the running-statistics update."""
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    dev = _dev()
+    B, H, W = 6, 23, 19
+    geo = engine.Geometry(B, H, W)
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    gen = torch.Generator(device=dev).manual_seed(cin)
+    x = torch.zeros(geo.alloc * cs_in, device=dev)
+    x[:geo.NQ * cs_in].view(B, geo.R, geo.P, cs_in)[:, :H + 1, :W + 1, :cin] = torch.rand((B, H + 1, W + 1, cin), device=dev, generator=gen)
+    w = (torch.rand((cout, cin, 2, 2), device=dev, generator=gen) - 0.5) * 0.1
+    bias = torch.rand(cout, device=dev, generator=gen) - 0.5
+    n = int(_lib.load().mmlf_packed_filter_h2_bytes(cs_in, cout))
+    pk = torch.empty(n // 4, device=dev)
+    call('mmlf_pack_filter_h2', ptr(w), ptr(pk), cout, cin, 0, 0, None, _lib.stream_ptr())
+    amax = x.abs().max().reshape(1)
+    z = geo.buf(cs_out, dev)
+    nblk = int(_lib.load().mmlf_conv2x2_blocks(cout, B, H, W))
+    partial = torch.full((nblk * 2 * cout + 8,), float('nan'), dtype=torch.float64, device=dev)
+    call('mmlf_conv2x2_h2', ptr(x), cs_in, cin, ptr(pk), ptr(bias), cout, ptr(z), cs_out, cs_out, geo.P + 1, H, W,
+         B, H, W, 0, None, 0, ptr(amax), ptr(z.absmax), ptr(partial), _lib.stream_ptr())
+    gamma, beta = torch.rand(cout, device=dev) + 0.5, torch.rand(cout, device=dev) - 0.5
+    out = {}
+    for mode in ('fused', 'two_pass'):
+        rm, rv = torch.full((cout,), 0.25, device=dev), torch.full((cout,), 2.0, device=dev)
+        c = torch.empty(4 * cout, device=dev)
+        if mode == 'fused':
+            call('mmlf_bn_stats_finalize', ptr(partial), nblk, cout, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5,
+                 ptr(c[2 * cout:]), ptr(c[3 * cout:]), ptr(c), ptr(c[cout:]), B, H, W, _lib.stream_ptr())
+        else:
+            part = torch.empty(2 * cout * 1024, dtype=torch.float64, device=dev)
+            call('mmlf_bn_stats_train', ptr(z), cs_out, cout, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5,
+                 ptr(c[2 * cout:]), ptr(c[3 * cout:]), ptr(c), ptr(c[cout:]), ptr(part), 1024, B, H, W, _lib.stream_ptr())
+        out[mode] = (c.cpu().numpy(), rm.cpu().numpy(), rv.cpu().numpy())
+    for a, b in zip(out['fused'], out['two_pass']):
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7)
+    assert float(z.absmax) == float(z.abs().max())
+
+
+def test_weight_absmax_table_and_slack_zeroing():
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    dev = _dev()
+    ts = [torch.randn(n, device=dev) * s for n, s in ((313600, 0.03), (7, 5.0), (19600, 1e-6), (1, 0.0))]
+    ptrs = torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64).to(dev)
+    sizes = torch.tensor([t.numel() for t in ts], dtype=torch.int64).to(dev)
+    out = torch.full((len(ts),), -1.0, device=dev)
+    call('mmlf_amax_many', ptr(ptrs), ptr(sizes), len(ts), ptr(out), _lib.stream_ptr())
+    assert out.tolist() == [float(t.abs().max()) for t in ts]
+    B, H, W, cs = 3, 5, 7, 8
+    geo = engine.Geometry(B, H, W)
+    buf = torch.full((geo.alloc * cs,), 3.0, device=dev)
+    call('mmlf_zero_slack', ptr(buf), cs, B, H, W, _lib.stream_ptr())
+    v = buf.cpu().numpy()
+    assert not v[:(geo.P + 1) * cs].any() and not v[geo.NQ * cs:].any()
+    assert (v[(geo.P + 1) * cs:geo.NQ * cs] == 3.0).all()
