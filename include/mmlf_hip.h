@@ -44,8 +44,8 @@ int mmlf_abi_version(void);
 int64_t mmlf_grid_alloc_positions(int B, int H, int W);
 /* number of floats of a packed filter for K input and N output channels (see mmlf_pack_filter) */
 int64_t mmlf_packed_filter_floats(int K, int N);
-/* floats of workspace mmlf_conv2x2_wgrad needs for (Cin, Cout) */
-int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout);
+/* floats of workspace mmlf_conv2x2_wgrad* needs for (Cin, Cout) on a (B, H, W) grid */
+int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout, int B, int H, int W);
 
 /* filter variants: the H / I streams run the shared stream net on a transposed / transposed+flipped
  * image (reference mmlf/model/feed_forward.py:236-256); the same result is obtained on the
@@ -79,23 +79,27 @@ int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void *packed, co
                        float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
                        int B, int H, int W, int relu, const float *relu_ref, int cs_ref, void *stream);
 
-/* 2-way f16 split variant ("f16x3"): every operand tensor is scaled by a power of two that brings its max |x|
- * into [2^14, 2^15), split exactly into two f16 (hi + lo, 22 mantissa bits) and each product evaluated as
- * hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with f32 accumulation; the scaling is undone exactly in
- * the epilogue.  Measured error vs a double reference: at the level of the exact-f32 MFMA chain
- * (tools/f16x2_accuracy.hip), at half the MFMA passes of the bf16 split.  in_amax: device scalar holding
- * max |in| (any upper bound within 2x is as good); out_amax (nullable): device scalar that receives
- * max(*out_amax, max |out|) by atomic max -- zero it before the first producer of a tensor.
- * `packed` holds mmlf_packed_filter_h2_bytes(K, N) bytes (the weights' own scale is stored behind them). */
+/* 2-way f16 split variant ("f16x3", the default arithmetic): an operand x is multiplied by a power of two s and
+ * rounded to two f16, x*s ~ hi + lo (2 x 11 = 22 significant bits, against float32's 24; NOT an exact split);
+ * each product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with f32 accumulation and the
+ * powers of two are undone exactly in the epilogue.  Measured error vs a double reference: at the level of the
+ * exact-f32 MFMA chain (tools/f16x2_accuracy.hip, tests/test_gpu_precision.py), at half the MFMA passes of the
+ * bf16 split.  The scales are LOCAL, so that small-magnitude regions keep their relative precision:
+ *  - activations: one scale per wave (32 output positions), from the maxima of the grid rows its taps read
+ *    (2-3 image rows of one patch); elements within 2^-18 of that maximum keep all 22 bits;
+ *  - weights: one scale per packed column (= output channel of the launch), chosen by mmlf_pack_filter_h2.
+ * "amax array" of a grid tensor (mmlf_amax_entries(B,H,W) floats): [0] = max |x| of the tensor, [1 + r] =
+ * max |x| of grid row r = q / P, all channels.  Every kernel that writes a grid tensor raises the entries of
+ * what it wrote by atomic max (`amax_out` arguments; upper bounds are as good as exact values);
+ * mmlf_zero_slack zeroes them together with the buffer's slack, before the tensor's first producer.
+ * `packed` holds mmlf_packed_filter_h2_bytes(K, N) bytes (the columns' 1/scale factors sit behind the planes). */
+int64_t mmlf_amax_entries(int B, int H, int W);
 int64_t mmlf_packed_filter_h2_bytes(int K, int N);
-int mmlf_pack_filter_h2(const float *w_oihw, void *packed, int Cout, int Cin, int variant, int dgrad,
-                        const float *w_amax /* nullable: device scalar max |w|, else computed here */, void *stream);
-/* max |x| of n float tensors in one launch: ptrs / sizes are DEVICE arrays (const float*[n], int64[n]) */
-int mmlf_amax_many(const void *ptrs, const void *sizes, int n, float *out, void *stream);
+int mmlf_pack_filter_h2(const float *w_oihw, void *packed, int Cout, int Cin, int variant, int dgrad, void *stream);
 int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
                     float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
                     int B, int H, int W, int relu, const float *relu_ref, int cs_ref,
-                    const float *in_amax, float *out_amax,
+                    const float *in_amax /* amax array of `in` */, float *out_amax /* nullable: amax array of `out` */,
                     double *bn_partial /* nullable: see mmlf_bn_stats_finalize */, void *stream);
 /* number of workgroups mmlf_conv2x2_h2 launches for this shape (= rows of bn_partial) */
 int mmlf_conv2x2_blocks(int N, int B, int H, int W);
@@ -113,8 +117,12 @@ int mmlf_conv2x2_wgrad_split(const float *in, int cs_in, int Cin, const float *g
                              int g_shift, float *gw_oihw, float *gb, int variant, int accumulate,
                              float *workspace, int B, int H, int W, void *stream);
 
-/* f16-split variant of mmlf_conv2x2_wgrad (see mmlf_conv2x2_h2): in_amax / g_amax are device scalars with
- * max |in| and max |g| */
+/* f16-split variant of mmlf_conv2x2_wgrad (see mmlf_conv2x2_h2): in_amax / g_amax are the operands' amax
+ * arrays.  The sum runs over all positions, so every 32-position chunk carries the same PRODUCT of operand
+ * scales (the tensors' global ones), split between the two operands per chunk by the maxima of the grid rows it
+ * reads: in * (sA * 2^x), g * (sG * 2^-x), x = half the difference of the operands' headroom.  A chunk keeps all
+ * 22 bits of both operands while its products are within 2^-36 of the launch's largest (smaller ones are below
+ * float32's own accumulation error of the sum). */
 int mmlf_conv2x2_wgrad_h2(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout,
                           int g_shift, float *gw_oihw, float *gb, int variant, int accumulate,
                           float *workspace, int B, int H, int W, const float *in_amax, const float *g_amax,
@@ -148,7 +156,7 @@ int mmlf_bn_stats_finalize(const double *partial, int nblocks, int C, const floa
  * feed_forward.py:134-135; writing a channel slice implements torch.cat, feed_forward.py:266-267) */
 int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *scale, const float *shift,
                        float *y, int cs_y, int c_off, int C_store, int B, int H, int W,
-                       float *amax_out /* nullable: atomic max |y| into a device scalar */, void *stream);
+                       float *amax_out /* nullable: amax array of y */, void *stream);
 /* BatchNorm2d + ReLU backward, pass 1: per-channel sums of g and g*zhat with
  * g = gy * (z*scale+shift > 0); emits dgamma, dbeta (accumulating) and coefficients k[3*C]. */
 int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
@@ -160,15 +168,16 @@ int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const float *z, in
 int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
                       const float *scale, const float *shift, const float *save_mean,
                       const float *coef, float *dz, int cs_dz, int B, int H, int W,
-                      float *amax_out /* nullable: atomic max |dz| */, void *stream);
+                      float *amax_out /* nullable: amax array of dz */, void *stream);
 
 /* (B, C, H, W) NCHW  <->  padded-grid NHWC (extent (H,W), grid offset (1,1), zero border, zero pad
  * channels).  replaces the .view / layout handling of feed_forward.py:226-232 and output[:, 0]. */
 int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int B, int H, int W,
-                   float *amax_out /* nullable: atomic max |x| */, void *stream);
+                   float *amax_out /* nullable: amax array of grid */, void *stream);
 int mmlf_unpack_nchw(const float *grid, int cs, float *nchw, int C, int B, int H, int W, void *stream);
-/* zero the slack of a freshly allocated grid buffer: positions [0, P+1) and [B*G, mmlf_grid_alloc_positions) */
-int mmlf_zero_slack(float *grid, int cs, int B, int H, int W, void *stream);
+/* zero the slack of a freshly allocated grid buffer: positions [0, P+1) and [B*G, mmlf_grid_alloc_positions),
+ * and (amax nullable) the buffer's amax array */
+int mmlf_zero_slack(float *grid, int cs, int B, int H, int W, float *amax, void *stream);
 
 /* UPR head (feed_forward.py:292-302, laplacian :9-12): posterior[b,k,y,x] from output[:,0:2]. */
 int mmlf_head_upr(const float *output_nchw, const float *grid108, float *posterior, int steps,

@@ -21,7 +21,7 @@ SIGNATURES = {
     'mmlf_abi_version': (_i, []),
     'mmlf_grid_alloc_positions': (_i64, [_i, _i, _i]),
     'mmlf_packed_filter_floats': (_i64, [_i, _i]),
-    'mmlf_wgrad_workspace_floats': (_i64, [_i, _i]),
+    'mmlf_wgrad_workspace_floats': (_i64, [_i, _i, _i, _i, _i]),
     'mmlf_pack_filter': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_conv2x2': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'mmlf_packed_filter_split_bytes': (_i64, [_i, _i]),
@@ -29,8 +29,8 @@ SIGNATURES = {
     'mmlf_conv2x2_split': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     'mmlf_conv2x2_wgrad_h2': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'mmlf_packed_filter_h2_bytes': (_i64, [_i, _i]),
-    'mmlf_pack_filter_h2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    'mmlf_amax_many': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'mmlf_amax_entries': (_i64, [_i, _i, _i]),
+    'mmlf_pack_filter_h2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_conv2x2_h2': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     'mmlf_conv2x2_blocks': (_i, [_i, _i, _i, _i]),
     'mmlf_bn_stats_finalize': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -43,7 +43,7 @@ SIGNATURES = {
     'mmlf_bn_bwd_reduce': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_bn_bwd_apply': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'mmlf_pack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
-    'mmlf_zero_slack': (_i, [_vp, _i, _i, _i, _i, _vp]),
+    'mmlf_zero_slack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     'mmlf_unpack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_head_upr': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_head_dpp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

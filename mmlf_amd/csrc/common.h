@@ -30,6 +30,24 @@ static inline int mmlf_launch_status(const char *what)
     return 0;
 }
 
+// per-device one-time setup (the library is called from one thread per device under nn.DataParallel)
+static inline int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    return d;
+}
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first()      // idempotent work only: a benign race repeats it
+    {
+        const int d = current_device();
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 // Padded-grid geometry of one launch (see include/mmlf_hip.h).
 struct Grid {
     int B, H, W, P, R, G;
@@ -48,6 +66,28 @@ static inline Grid make_grid(int B, int H, int W)
 
 // slack: taps reach P+1 past a tile; the split kernel's last DMA piece reads 64 positions more
 static inline long long grid_alloc_positions(const Grid &g) { return g.NQpad + g.P + 8 + 64; }
+
+// ---- max |x| bookkeeping of the f16-split arithmetic ("amax array" of a grid tensor) ----
+// [0] = max |x| over the whole tensor, [1 + r] = max |x| over grid row r = q / P (all channels).  Entries are
+// upper bounds raised by atomic max (non-negative floats order like their bit patterns); mmlf_zero_slack zeroes
+// them before the first producer of the tensor runs.  Rows past B*R (tile padding, tap slack) stay zero.
+static inline long long amax_entries(const Grid &g) { return 1 + (g.NQpad + 2 * g.P + 64) / g.P + 2; }
+
+// n / d == (n * m) >> sh for 0 <= n < 2^31 (Granlund-Montgomery round-up magic, N = 31)
+struct Magic { unsigned m; int sh; };
+static inline Magic make_magic(unsigned d)
+{
+    int l = 0;
+    while ((1ull << l) < d) ++l;
+    Magic r;
+    r.sh = 31 + l;
+    r.m = (unsigned)(((1ull << r.sh) + d - 1) / d);
+    return r;
+}
+__host__ __device__ static inline unsigned fastdiv(unsigned n, Magic g)
+{
+    return (unsigned)(((unsigned long long)n * g.m) >> g.sh);
+}
 
 // supported MFMA N-tile counts (32 output channels each)
 static inline int pick_nt(int N)
@@ -72,12 +112,34 @@ __host__ __device__ static inline int master_tap(int t, int variant)
 // Running max |x| of a tensor in a device scalar (non-negative floats order like their bit patterns).
 // Every thread of the block calls it with its own maximum; the atomic is skipped when the scalar already
 // holds a larger value (a stale read only costs an extra atomic), so a launch issues few of them.
-__device__ __forceinline__ void mmlf_amax_update(float m, float *amax)
+// fire-and-forget form for hot epilogues: no read of the slot, nothing to wait for
+__device__ __forceinline__ void mmlf_amax_raise_nowait(float *slot_f, float m)
+{
+    (void)__hip_atomic_fetch_max(reinterpret_cast<unsigned *>(slot_f), __float_as_uint(m), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mmlf_amax_raise(float *slot_f, float m)
+{
+    const unsigned bits = __float_as_uint(m);
+    unsigned *slot = reinterpret_cast<unsigned *>(slot_f);
+    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+}
+__device__ __forceinline__ float mmlf_wave_max(float m)
 {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) {
-        const unsigned bits = __float_as_uint(m);
-        unsigned *slot = reinterpret_cast<unsigned *>(amax);
-        if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    return m;
+}
+__device__ __forceinline__ void mmlf_amax_update(float m, float *amax)
+{
+    m = mmlf_wave_max(m);
+    if ((threadIdx.x & 63) == 0) mmlf_amax_raise(amax, m);
+}
+// the same for a kernel whose workgroup writes ONE grid row: raises the tensor's and the row's entry
+__device__ __forceinline__ void mmlf_amax_update_row(float m, float *amax, int row)
+{
+    m = mmlf_wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        mmlf_amax_raise(amax, m);
+        mmlf_amax_raise(amax + 1 + row, m);
     }
 }

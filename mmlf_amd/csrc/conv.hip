@@ -52,9 +52,11 @@ struct ConvArgs {
     long long NQ;
     int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
     int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6s_kernel)
-    const float *in_amax;                // f16 split: max |in| (device scalar) -> power-of-two operand scale
-    const float *w_scale;                // f16 split: the scale the packed weights carry (device scalar)
-    float *out_amax;                     // optional: running max |out| (device scalar, atomic max)
+    const float *in_amax;                // f16 split: amax array of `in` (common.h): per-wave power-of-two operand scales
+    const float *w_unscale;              // f16 split: 1 / (power-of-two scale of packed column n), [NP]
+    float *out_amax;                     // optional: amax array of `out` (tensor and grid-row maxima, atomic max)
+    Magic divP, divR;                    // q / P and row / R without integer division
+    int R;
     double *bn_partial;                  // optional (f16 split): per-workgroup sums of out and out^2 per channel,
                                          // [block][2][n_true] doubles, the input of the BatchNorm finalize
 };
@@ -71,10 +73,10 @@ struct ConvArgs {
 #define MMLF_BUF_FLAGS 0x00020000   // raw dword buffer (DATA_FORMAT_32), no swizzle
 __device__ __forceinline__ unsigned wave_row_mask(const ConvArgs &a, long long Q0, int w, int lane)
 {
-    const int qrow = (int)Q0 + 32 * w + (lane & 31);
-    const int rem = qrow % a.G;
-    const int y = rem / a.P, x = rem - y * a.P;
-    return (unsigned)__ballot(qrow < a.NQ && y < a.vh && x < a.vw);
+    const unsigned qrow = (unsigned)Q0 + 32 * w + (lane & 31);
+    const unsigned row = fastdiv(qrow, a.divP);                 // global grid row
+    const int x = (int)(qrow - row * a.P), y = (int)(row - fastdiv(row, a.divR) * a.R);
+    return (unsigned)__ballot((long long)qrow < a.NQ && y < a.vh && x < a.vw);
 }
 
 // 32x32 tiling: lane (i, kh) holds column i of each 32-column block, rows (r&3) + 8*(r>>2) + 4*kh.
@@ -190,39 +192,47 @@ __device__ __forceinline__ void split2_pair_f16(float a, float b, float s, unsig
     h = __builtin_bit_cast(unsigned, hh);
     l = __builtin_bit_cast(unsigned, ll);
 }
-// max |x| of a float array into *out (non-negative floats order like their bit patterns)
-__global__ void amax_kernel(const float *__restrict__ x, long long n, float *__restrict__ out)
+// f16-split filter packing: [chunk][plane(2)][tap(4)][NP][8 f16] of w * scale[n], one workgroup per packed
+// column n (= output channel of the launch).  Every column carries its own power-of-two scale (its max |w|
+// goes to [2^14, 2^15)), so an output channel whose weights are small as a whole keeps its 22 bits;
+// unscale[n] = 1 / scale[n] is what the convolution's epilogue multiplies column n by.
+__global__ __launch_bounds__(256) void pack_filter_h2_kernel(const float *__restrict__ w, unsigned short *__restrict__ out,
+                                                             int Cout, int Cin, int variant, int dgrad, int nchunk,
+                                                             int NP, float *__restrict__ unscale)
 {
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    auto at = [&](int k, int tap) -> size_t {      // OIHW index of (packed row k, column n, master tap)
+        return dgrad ? ((size_t)k * Cin + n) * 4 + tap : ((size_t)n * Cin + k) * 4 + tap;
+    };
     float m = 0.f;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(x[i]));
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(out), __float_as_uint(m));
-}
-// f16-split filter packing: [chunk][plane(2)][tap(4)][NP][8 f16] of w * scale; *scale_out = scale
-__global__ void pack_filter_h2_kernel(const float *__restrict__ w, unsigned short *__restrict__ out, int Cout,
-                                      int Cin, int variant, int dgrad, int nchunk, int NP,
-                                      const float *__restrict__ w_amax, float *__restrict__ scale_out)
-{
-    const float sc = pow2_scale_for(*w_amax);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *scale_out = sc;
-    const long long total = (long long)nchunk * 4 * NP * 8;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int j = idx & 7;
-        long long r = idx >> 3;
-        const int n = r % NP; r /= NP;
-        const int t = r & 3; r >>= 2;
-        const int c = (int)r;
-        const int k = 8 * c + j;
-        int ci, co, tsrc;
-        if (!dgrad) { ci = k; co = n; tsrc = t; }
-        else { co = k; ci = n; tsrc = 3 - t; }
-        float v = 0.f;
-        if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * 4 + master_tap(tsrc, variant)] * sc;
-        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
-        out[((((size_t)c * 2 + 0) * 4 + t) * NP + n) * 8 + j] = __builtin_bit_cast(unsigned short, h);
-        out[((((size_t)c * 2 + 1) * 4 + t) * NP + n) * 8 + j] = __builtin_bit_cast(unsigned short, l);
+    if (n < N)
+        for (int e = tid; e < 4 * K; e += 256) m = fmaxf(m, fabsf(w[at(e >> 2, e & 3)]));
+    __shared__ float red[4];
+    m = mmlf_wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    const float sc = pow2_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (tid == 0) unscale[n] = 1.f / sc;
+    for (int e = tid; e < 4 * nchunk; e += 256) {
+        const int c = e >> 2, t = e & 3;
+        const int tap = master_tap(dgrad ? 3 - t : t, variant);
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * c + j;
+            const float v = (k < K && n < N) ? w[at(k, tap)] * sc : 0.f;
+            const _Float16 hh = (_Float16)v, ll = (_Float16)(v - (float)hh);
+            h[j] = __builtin_bit_cast(unsigned short, hh);
+            l[j] = __builtin_bit_cast(unsigned short, ll);
+        }
+        uint4 vh, vl;
+        vh.x = h[0] | (unsigned)h[1] << 16; vh.y = h[2] | (unsigned)h[3] << 16;
+        vh.z = h[4] | (unsigned)h[5] << 16; vh.w = h[6] | (unsigned)h[7] << 16;
+        vl.x = l[0] | (unsigned)l[1] << 16; vl.y = l[2] | (unsigned)l[3] << 16;
+        vl.z = l[4] | (unsigned)l[5] << 16; vl.w = l[6] | (unsigned)l[7] << 16;
+        *reinterpret_cast<uint4 *>(out + ((((size_t)c * 2 + 0) * 4 + t) * NP + n) * 8) = vh;
+        *reinterpret_cast<uint4 *>(out + ((((size_t)c * 2 + 1) * 4 + t) * NP + n) * 8) = vl;
     }
 }
 
@@ -266,9 +276,13 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 16x16 tiling: lane (r16, q4) holds column r16 of each 16-column block and rows 16*mb + 4*q4 + r.
+// unscale_a undoes this wave's activation scale, a.w_unscale[n] column n's weight scale (powers of two: exact).
+// With a.out_amax the wave also raises the output's amax array: its 32 positions lie in at most two grid rows
+// when P >= 32 (exact row maxima); for smaller pitches the rows behind the first get the common maximum
+// (an upper bound, which is all the consumers need).
 template <int G>
 __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (&acc)[2][G], long long Q0, int w,
-                                                int r16, int q4, float unscale_a, float unscale_w, float &run_max,
+                                                int r16, int q4, float unscale_a, float &run_max,
                                                 double *stats /* this wave's [16*G][2] sums, or null */)
 {
     const unsigned m = wave_row_mask(a, Q0, w, r16 + 16 * q4) >> (4 * q4);
@@ -281,11 +295,15 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
     unsigned lo = ((unsigned)(4 * q4) * a.cs_out + r16) * 4u;
     unsigned lr = ((unsigned)(4 * q4) * a.cs_ref + r16) * 4u;
     asm volatile("" : "+v"(lo), "+v"(lr));   // see conv_epilogue
+    float mk[8];                             // max |out| per position this lane holds (over the column blocks)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mk[k] = 0.f;
 #pragma unroll
     for (int nb = 0; nb < G; ++nb) {
         const int ch = 16 * nb + r16;
         if (ch >= a.n_store) continue;
         const float bvn = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
+        const float uw = a.w_unscale ? a.w_unscale[ch] : 1.f;
         unsigned keep = m;
         float s1 = 0.f, s2 = 0.f;
         if (has_ref) {
@@ -301,10 +319,10 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int rc = 16 * (k >> 2) + (k & 3);
-            float v = acc[k >> 2][nb][k & 3] * unscale_a * unscale_w + bvn;   // exact: powers of two (1 on the bf16 path)
+            float v = acc[k >> 2][nb][k & 3] * unscale_a * uw + bvn;   // exact: powers of two (1 on the bf16 path)
             if (a.relu) v = fmaxf(v, 0.f);
             v = (keep >> rc & 1) ? v : 0.f;
-            run_max = fmaxf(run_max, fabsf(v));
+            mk[k] = fmaxf(mk[k], fabsf(v));
             s1 += v;
             s2 = fmaf(v, v, s2);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ob,
@@ -319,6 +337,68 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
             }
         }
     }
+    if (a.out_amax) {
+        const unsigned d0 = (unsigned)qb;                       // first destination position of the wave
+        const unsigned rd0 = fastdiv(d0, a.divP);
+        const int nfirst = (int)((rd0 + 1) * (unsigned)a.P - d0);   // wave positions [0, nfirst) lie in grid row rd0
+        float m_lo = 0.f, m_hi = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int pos = 16 * (k >> 2) + 4 * q4 + (k & 3);
+            if (pos < nfirst) m_lo = fmaxf(m_lo, mk[k]);
+            else m_hi = fmaxf(m_hi, mk[k]);
+        }
+        m_lo = mmlf_wave_max(m_lo);
+        m_hi = mmlf_wave_max(m_hi);
+        if (r16 + 16 * q4 == 0) {
+            if (m_lo > 0.f) mmlf_amax_raise_nowait(a.out_amax + 1 + rd0, m_lo);
+            if (m_hi > 0.f) {
+                const unsigned rdl = fastdiv(d0 + 31, a.divP);
+                for (unsigned r = rd0 + 1; r <= rdl; ++r) mmlf_amax_raise_nowait(a.out_amax + 1 + r, m_hi);
+            }
+            run_max = fmaxf(run_max, fmaxf(m_lo, m_hi));        // lane 0 carries the tensor maximum
+        }
+    }
+}
+
+// f16 split: the power-of-two scale wave w of tile Q0 applies to its activation operand.  The wave's valid
+// outputs q read in[q + {0, 1, P, P+1}], i.e. grid rows row(q0) .. row(q0 + 31) + 1 (no row is added behind a
+// patch's last row: its outputs are never valid), so the scale comes from those rows' maxima alone: a wave's
+// precision does not depend on what the rest of the tensor holds (neighbouring patches, far-away rows).
+// Two halves so that the row loads of the NEXT tile fly during this tile's epilogue: gather (per-lane maximum of
+// the rows lane, lane + 64, ... of the range) and finish (wave maximum -> scale).
+__device__ __forceinline__ float wave_operand_amax_gather(const ConvArgs &a, long long Q0, int w, int lane)
+{
+    const long long q0 = Q0 + 32 * w;
+    float m = 0.f;
+    if (q0 < a.NQ) {                                             // wave-uniform; else nothing valid in this wave
+        const long long ql = q0 + 31 < a.NQ ? q0 + 31 : a.NQ - 1;
+        const unsigned r0 = fastdiv((unsigned)q0, a.divP);
+        unsigned r1 = fastdiv((unsigned)ql, a.divP);
+        r1 += (r1 - fastdiv(r1, a.divR) * (unsigned)a.R != (unsigned)(a.R - 1)) ? 1u : 0u;
+        for (unsigned r = r0 + lane; r <= r1; r += 64) m = fmaxf(m, a.in_amax[1 + r]);
+    }
+    return m;
+}
+__device__ __forceinline__ float wave_operand_scale(float gathered)
+{
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(pow2_scale_for(mmlf_wave_max(gathered)))));
+}
+
+// The launch arguments as stored in the kernel-argument segment, behind a pointer the optimiser cannot see through:
+// what is read through it is loaded where it is used (scalar loads) instead of living in SGPRs across the main
+// loop.  The persistent kernel's main loop needs a handful of arguments, its epilogue some twenty -- kept live,
+// they push the loop's own scalars into spill lanes (0.3 ms of an 8 ms launch).
+typedef const __attribute__((address_space(4))) ConvArgs *ConvKernArgs;
+__device__ __forceinline__ ConvArgs late_args()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    ConvKernArgs p = (ConvKernArgs)__builtin_amdgcn_kernarg_segment_ptr();   // ConvArgs is the kernel's first parameter
+    asm volatile("" : "+s"(p));
+    return *p;
+#else
+    return ConvArgs();
+#endif
 }
 
 // 512 threads = 8 waves; tile = 256 positions x 16*G output channels; wave w owns positions
@@ -435,14 +515,13 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     if (tile >= ntiles) return;
     // optional BatchNorm statistics of the output: per-wave double sums behind the two pipeline buffers
     double *stats_all = reinterpret_cast<double *>(lds + 2 * BUF_F4);        // [8 waves][NP][2]
-    if (a.bn_partial)
+    if (late_args().bn_partial)
         for (int k = tid; k < 8 * NP * 2; k += 512) stats_all[k] = 0.0;      // ordered by the barrier below
     // f16 split: operand scales (powers of two) and what undoes them in the epilogue
-    float scale_a = 1.f, unscale_a = 1.f, unscale_w = 1.f, run_max = 0.f;
+    float scale_a = 1.f, unscale_a = 1.f, run_max = 0.f;
     if constexpr (PL == 2) {
-        scale_a = pow2_scale_for(*a.in_amax);
+        scale_a = wave_operand_scale(wave_operand_amax_gather(late_args(), (long long)tile * MMLF_TILE, w, lane));
         unscale_a = 1.f / scale_a;
-        unscale_w = 1.f / *a.w_scale;
     }
     X6_DMA_SLOT(ntile, nc, 0, 0);
     X6_DMA_SLOT(ntile, nc, 0, 1);
@@ -539,8 +618,13 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
         // BEFORE the epilogue, so that its stores (same counter) stay in flight across the barrier
         X6_DMA_WAIT();
         if (++c == a.nchunk) {
-            conv_epilogue16<G>(a, acc, (long long)tile * MMLF_TILE, w, r16, q4, unscale_a, unscale_w, run_max,
-                               a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
+            const ConvArgs e = late_args(); // epilogue-only arguments: loaded here, dead again at the barrier
+            float next_amax = 0.f;          // the next tile's row maxima: loads in flight during the epilogue
+            if constexpr (PL == 2)
+                if (tile + (int)gridDim.x < ntiles)
+                    next_amax = wave_operand_amax_gather(e, (long long)(tile + gridDim.x) * MMLF_TILE, w, lane);
+            conv_epilogue16<G>(e, acc, (long long)tile * MMLF_TILE, w, r16, q4, unscale_a, run_max,
+                               e.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -549,18 +633,25 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
                     for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
             c = 0;
             tile += gridDim.x;
+            if constexpr (PL == 2) {
+                if (tile < ntiles) {
+                    scale_a = wave_operand_scale(next_amax);
+                    unscale_a = 1.f / scale_a;
+                }
+            }
         }
         __syncthreads();
         buf ^= 1;
     }
-    if (a.out_amax) mmlf_amax_update(run_max, a.out_amax);      // at most one atomic per wave per launch
-    if (a.bn_partial) {                                         // the loop's last barrier ordered the wave sums
-        for (int k = tid; k < 2 * a.n_true; k += 512) {
-            const int ch = k % a.n_true, which = k / a.n_true;
+    const ConvArgs e = late_args();
+    if (e.out_amax) mmlf_amax_update(run_max, e.out_amax);      // at most one atomic per wave per launch
+    if (e.bn_partial) {                                         // the loop's last barrier ordered the wave sums
+        for (int k = tid; k < 2 * e.n_true; k += 512) {
+            const int ch = k % e.n_true, which = k / e.n_true;
             double t = 0.0;
 #pragma unroll
             for (int ww = 0; ww < 8; ++ww) t += stats_all[((size_t)ww * NP + ch) * 2 + which];
-            a.bn_partial[((size_t)blockIdx.x * 2 + which) * a.n_true + ch] = t;
+            e.bn_partial[((size_t)blockIdx.x * 2 + which) * e.n_true + ch] = t;
         }
     }
 #undef X6_DMA_PIECE
@@ -712,7 +803,8 @@ struct WgradArgs {
     float *part;          // [nsplit][4][CIP][NP]
     long long NQpad;
     int cs_in, cin, cs_g, g_shift, P, nsplit, nslice, chunks_per_split, nchunks;
-    const float *in_amax, *g_amax;   // f16 split: max |in|, max |g| (device scalars)
+    const float *in_amax, *g_amax;   // f16 split: amax arrays of in and g (common.h)
+    const float *chunk_scales;       // f16 split: [nchunks][2] power-of-two operand scales (wgrad_chunk_scales_kernel)
 };
 
 #define WG_KQ 32  // positions per chunk
@@ -884,18 +976,74 @@ template <int PL> __device__ __forceinline__ constexpr int term_b(int t)
 {
     return PL == 3 ? (t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 1 : t == 3 ? 0 : t == 4 ? 1 : 0) : (t == 1 ? 1 : 0);
 }
-// f16 split: what undoes the operand scales for partial-sum row `row` (the ones row carries no input scale)
-struct WgradScales { float sa, sg, inv_sa, inv_sg; };
+// f16 split of the weight gradient.  The sum runs over all positions, so every chunk of 32 positions must carry
+// the SAME product of operand scales -- but the split between the two operands is free per chunk:
+//   in * (sA * 2^x)  and  g * (sG * 2^-x),   sA, sG = the tensors' global scales (max |.| -> [2^14, 2^15)),
+// with x chosen per chunk by wgrad_chunk_scales_kernel from the maxima of the grid rows the chunk reads: if the
+// chunk's activations sit u binades below their tensor's maximum and its gradients v binades below theirs,
+// x = (u - v) / 2 gives each operand (u + v) / 2 binades of headroom loss instead of u resp. v, so a chunk keeps
+// all 22 bits of both operands as long as its products are within 2^-36 of the largest products of the launch
+// (smaller ones are below float32's accumulation error of the sum anyway).  The ones row that yields the bias
+// gradient is staged as 1 / sA, i.e. 2^x after scaling: exact in f16 for -24 <= x <= 15, which bounds x.
+struct WgradScales { float inv_sa, inv_sg; };
 template <int PL> __device__ __forceinline__ WgradScales wgrad_scales(const WgradArgs &a)
 {
-    WgradScales s = {1.f, 1.f, 1.f, 1.f};
+    WgradScales s = {1.f, 1.f};
     if constexpr (PL == 2) {
-        s.sa = pow2_scale_for(*a.in_amax);
-        s.sg = pow2_scale_for(*a.g_amax);
-        s.inv_sa = 1.f / s.sa;
-        s.inv_sg = 1.f / s.sg;
+        s.inv_sa = 1.f / pow2_scale_for(a.in_amax[0]);
+        s.inv_sg = 1.f / pow2_scale_for(a.g_amax[0]);
     }
     return s;
+}
+// operand scales of chunk c (PL == 3: no scaling)
+template <int PL> __device__ __forceinline__ void wgrad_chunk_scale(const WgradArgs &a, int c, float &sa, float &sg)
+{
+    if constexpr (PL == 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(a.chunk_scales + 2 * (size_t)c);
+        sa = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v.x)));
+        sg = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v.y)));
+    } else {
+        sa = 1.f; sg = 1.f;
+    }
+}
+struct ChunkScaleArgs {
+    const float *in_amax, *g_amax;
+    float *out;                      // [nchunks][2]
+    long long NQ;
+    int nchunks, P, g_shift, nrows;
+    Magic divP;
+};
+__device__ __forceinline__ int pow2_exponent(float p) { return (int)(__float_as_uint(p) >> 23) - 127; }
+__global__ __launch_bounds__(256) void wgrad_chunk_scales_kernel(ChunkScaleArgs a)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.nchunks) return;
+    const float sA = pow2_scale_for(a.in_amax[0]), sG = pow2_scale_for(a.g_amax[0]);
+    const long long q0 = (long long)c * WG_KQ;
+    int x = 0;
+    if (q0 < a.NQ) {
+        // activations: the chunk stages in[q0 .. q0 + 32 + P] (its positions' four taps); gradients: g[q + g_shift].
+        // EVERY staged element must stay inside the f16 range, also those that only meet zero gradients (an
+        // overflow would put inf * 0 into the sum), so all rows the staging touches count.
+        const long long ql = q0 + WG_KQ - 1;
+        const unsigned r0 = fastdiv((unsigned)q0, a.divP);
+        unsigned r1 = fastdiv((unsigned)(ql + a.P + 1), a.divP);
+        if (r1 >= (unsigned)a.nrows) r1 = a.nrows - 1;
+        float ma = 0.f, mg = 0.f;
+        for (unsigned r = r0; r <= r1; ++r) ma = fmaxf(ma, a.in_amax[1 + r]);
+        const unsigned g0 = fastdiv((unsigned)(q0 + a.g_shift), a.divP);
+        unsigned g1 = fastdiv((unsigned)(ql + a.g_shift), a.divP);
+        if (g1 >= (unsigned)a.nrows) g1 = a.nrows - 1;
+        for (unsigned r = g0; r <= g1; ++r) mg = fmaxf(mg, a.g_amax[1 + r]);
+        // headroom (binades) of the chunk's operands under the global scales; an all-zero operand takes any scale
+        const int u = ma > 0.f ? pow2_exponent(pow2_scale_for(ma)) - pow2_exponent(sA) : 60;
+        const int v = mg > 0.f ? pow2_exponent(pow2_scale_for(mg)) - pow2_exponent(sG) : 60;
+        const int uu = u < 0 ? 0 : u, vv = v < 0 ? 0 : v;        // (row maxima never exceed the tensor's)
+        x = (uu - vv) >> 1;                                        // floor
+        x = x > 15 ? 15 : (x < -24 ? -24 : x);
+    }
+    a.out[2 * (size_t)c] = sA * exp2f((float)x);
+    a.out[2 * (size_t)c + 1] = sG * exp2f((float)-x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -984,14 +1132,14 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
                 if (ch + 1 == a.cin) v.y = sc.inv_sa;                                                       \
                 if (ch + 2 == a.cin) v.z = sc.inv_sa;                                                       \
                 if (ch + 3 == a.cin) v.w = sc.inv_sa;                                                       \
-                split_store4_pl<PL>(v, sc.sa, As + seg * PL * A_PLANE + pix * ROWA + 8 * f, A_PLANE);       \
+                split_store4_pl<PL>(v, st_sa, As + seg * PL * A_PLANE + pix * ROWA + 8 * f, A_PLANE);       \
             }                                                                                               \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
             const int idx = tid + 256 * j;                                                                  \
             if (idx < WG_KQ * FG) {                                                                         \
                 const int row = idx / FG, f = idx - row * FG;                                               \
-                split_store4_pl<PL>(rg[j], sc.sg, Gs + row * ROWG + 8 * f, G_PLANE);                        \
+                split_store4_pl<PL>(rg[j], st_sg, Gs + row * ROWG + 8 * f, G_PLANE);                        \
             }                                                                                               \
         }                                                                                                   \
     } while (0)
@@ -1000,9 +1148,11 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
     const char *a_lane = As + (t >> 1) * PL * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWA + 8 * tp;
     const char *g_lane = Gs + (4 * q4 + tq) * ROWG + 8 * tp;
 
+    float st_sa = 1.f, st_sg = 1.f;          // operand scales of the chunk being staged
     if (c_begin < c_end) {
         WN_GLOAD(c_begin);
         for (int c = c_begin; c < c_end; ++c) {
+            wgrad_chunk_scale<PL>(a, c, st_sa, st_sg);
             WN_LSTORE();
             __syncthreads();
             if (c + 1 < c_end) WN_GLOAD(c + 1);
@@ -1139,21 +1289,23 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         v.y = ch + 1 == a.cin ? sc.inv_sa : v.y;                                                                  \
         v.z = ch + 2 == a.cin ? sc.inv_sa : v.z;                                                                  \
         v.w = ch + 3 == a.cin ? sc.inv_sa : v.w;                                                                  \
-        split_store4_pl<PL>(v, sc.sa, (dst) + seg * PL * A_PLANE + pix * ROWA + 8 * f, A_PLANE);            \
+        split_store4_pl<PL>(v, st_sa, (dst) + seg * PL * A_PLANE + pix * ROWA + 8 * f, A_PLANE);            \
     } while (0)
 #define WW_STORE_G(j, dst)                                                                                  \
     do {                                                                                                    \
         const int idx = min(tid + 512 * (j), WG_KQ * FG - 1);                                               \
         const int row = idx / FG, f = idx - row * FG;                                                       \
-        split_store4_pl<PL>(rg[j], sc.sg, (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);                   \
+        split_store4_pl<PL>(rg[j], st_sg, (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);                   \
     } while (0)
 
     const int tq = (lane & 15) >> 2, tp = lane & 3;
     const int a_off = (t >> 1) * PL * A_PLANE + ((t & 1) + 4 * q4 + tq) * ROWA + 8 * tp;
     const int g_off = A_BYTES + (4 * q4 + tq) * ROWG + 8 * tp + 32 * NBH * h;
 
+    float st_sa = 1.f, st_sg = 1.f;          // operand scales of the chunk being staged
     if (c_begin < c_end) {
         WW_GLOAD(c_begin);
+        wgrad_chunk_scale<PL>(a, c_begin, st_sa, st_sg);
 #pragma unroll
         for (int j = 0; j < NA; ++j) WW_STORE_A(j, smem);
 #pragma unroll
@@ -1192,6 +1344,7 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     } while (0)
         static_assert(NA + NG <= NBH, "one staging piece per column block");
         for (int c = c_begin; c + 1 < c_end; ++c) {
+            wgrad_chunk_scale<PL>(a, c + 1, st_sa, st_sg);
             WW_CHUNK(true);
             if (c + 2 < c_end) WW_GLOAD(c + 2);
             __syncthreads();
@@ -1290,7 +1443,8 @@ static inline bool wgrad16_cfg(int Cin, int Cout, Wgrad16Cfg *c)
     return true;
 }
 
-extern "C" int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout)
+// partial sums of the position splits (largest of the kernels' layouts)
+static int64_t wgrad_partial_floats(int Cin, int Cout)
 {
     const int nt = pick_nt(Cout);
     if (nt < 0) return -1;
@@ -1301,7 +1455,14 @@ extern "C" int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout)
         const int64_t m = (int64_t)c.nsplit * 4 * (c.nslice * 16 * c.mb) * (16 * c.nb);
         if (m > n) n = m;
     }
-    return n;
+    return (n + 3) / 4 * 4;
+}
+
+extern "C" int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout, int B, int H, int W)
+{
+    const int64_t n = wgrad_partial_floats(Cin, Cout);
+    if (n < 0 || B <= 0 || H <= 0 || W <= 0) return -1;
+    return n + 2 * (make_grid(B, H, W).NQpad / WG_KQ);      // + the f16 split's per-chunk operand scales
 }
 
 extern "C" int mmlf_pack_filter(const float *w, float *packed, int Cout, int Cin, int variant, int dgrad,
@@ -1325,11 +1486,10 @@ template <int NT>
 static int launch_conv(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
     constexpr size_t lds = 2 * (4 * 320 + 4 * 2 * NT * 32) * sizeof(float4);
-    static bool attr_done = false;  // idempotent; a benign race only repeats the call
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     hipLaunchKernelGGL(conv4tap_kernel<NT>, dim3((unsigned)ntiles), dim3(512), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2");
@@ -1354,6 +1514,8 @@ extern "C" int mmlf_conv2x2(const float *in, int cs_in, int K, const float *pack
     a.in = in; a.wp = packed; a.bias = bias; a.out = out; a.ref = relu_ref;
     a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
     a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
+    a.divP = make_magic((unsigned)g.P); a.divR = make_magic((unsigned)g.R); a.R = g.R;
+    MMLF_CHECK_ARG(g.NQpad + g.P + 64 < (1ll << 31), "mmlf_conv2x2: batch x image too large for 32-bit grid positions");
     const long long ntiles = g.NQpad / MMLF_TILE;
     hipStream_t st = (hipStream_t)stream;
     switch (nt) {
@@ -1376,11 +1538,10 @@ template <int MB, int NB, int PL>
 static int launch_wgrad16(const WgradArgs &a, hipStream_t st)
 {
     constexpr size_t lds = 2 * PL * 34 * 32 * (MB | 1) + PL * WG_KQ * 32 * (NB | 1);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6n_kernel<MB, NB, PL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     hipLaunchKernelGGL((wgrad4tap_x6n_kernel<MB, NB, PL>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(256), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
@@ -1390,11 +1551,10 @@ template <int PL>
 static int launch_wgrad_wide(const WgradArgs &a, hipStream_t st)
 {
     constexpr size_t lds = 2 * (2 * PL * 34 * 32 * (3 | 1) + PL * WG_KQ * 32 * (18 | 1));
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6w_kernel<3, 9, PL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
     }
     hipLaunchKernelGGL((wgrad4tap_x6w_kernel<3, 9, PL>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(512), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
@@ -1459,7 +1619,7 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
     WgradArgs a;
     a.in = in; a.g = g; a.part = workspace; a.NQpad = gr.NQpad;
     a.cs_in = cs_in; a.cin = Cin; a.cs_g = cs_g; a.g_shift = g_shift; a.P = gr.P;
-    a.in_amax = in_amax; a.g_amax = g_amax;
+    a.in_amax = in_amax; a.g_amax = g_amax; a.chunk_scales = nullptr;
     a.nslice = (Cin + 1 + 31) / 32;   // +1: the ones row that yields the bias gradient
     a.nsplit = wgrad_nsplit(a.nslice);
     a.nchunks = (int)(gr.NQpad / WG_KQ);
@@ -1467,6 +1627,16 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
     hipStream_t st = (hipStream_t)stream;
     int rc;
     Wgrad16Cfg c;
+    if (planes == 2) {          // per-chunk operand scales, behind the partial sums in the workspace
+        MMLF_CHECK_ARG(gr.NQpad + 2 * gr.P + 64 < (1ll << 31), "mmlf_conv2x2_wgrad_h2: batch x image too large");
+        ChunkScaleArgs ca;
+        ca.in_amax = in_amax; ca.g_amax = g_amax; ca.out = workspace + wgrad_partial_floats(Cin, Cout);
+        ca.NQ = gr.NQ; ca.nchunks = a.nchunks; ca.P = gr.P; ca.g_shift = g_shift;
+        ca.nrows = (int)amax_entries(gr) - 1;
+        ca.divP = make_magic((unsigned)gr.P);
+        hipLaunchKernelGGL(wgrad_chunk_scales_kernel, dim3((a.nchunks + 255) / 256), dim3(256), 0, st, ca);
+        a.chunk_scales = ca.out;
+    }
     if (planes && wgrad16_cfg(Cin, Cout, &c)) {
         a.nslice = c.nslice;
         a.nsplit = c.nsplit;
@@ -1529,15 +1699,14 @@ extern "C" int mmlf_pack_filter_split(const float *w, void *packed, int Cout, in
 
 static int device_cus()
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+    static int cus[64] = {};                 // per device ordinal (a benign race only repeats the query)
+    const int dev = current_device();
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
     }
-    return cus;
+    return cus[dev];
 }
 
 // persistent launches: one workgroup per CU (two for the narrow variants), each walks tiles b, b+grid, ...
@@ -1552,11 +1721,10 @@ static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
     constexpr size_t lds_pipe = 2 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
     constexpr size_t lds_stats = 8 * (G * 16) * 2 * sizeof(double);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_pipe + (PL == 2 ? lds_stats : 0)));
-        attr_done = true;
     }
     const size_t lds = lds_pipe + (a.bn_partial ? lds_stats : 0);
     const long long grid = conv_split_blocks(G, ntiles);
@@ -1601,10 +1769,12 @@ static int conv_split_impl(const char *who, int planes, const float *in, int cs_
     a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
     a.in_amax = in_amax; a.out_amax = out_amax; a.bn_partial = bn_partial;
     MMLF_CHECK_ARG(!bn_partial || (planes == 2 && N_store >= N), "%s: BatchNorm statistics need the f16 split path", who);
-    // the f16-packed filter ends with the scale it carries
-    a.w_scale = planes == 2 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed) +
-                                                                (size_t)(cs_in / 8) * 8 * np * 16)
-                            : nullptr;
+    // the f16-packed filter ends with its columns' unscale factors
+    a.w_unscale = planes == 2 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed) +
+                                                                  (size_t)(cs_in / 8) * 8 * np * 16)
+                              : nullptr;
+    a.divP = make_magic((unsigned)g.P); a.divR = make_magic((unsigned)g.R); a.R = g.R;
+    MMLF_CHECK_ARG(g.NQpad + g.P + 64 < (1ll << 31), "%s: batch x image too large for 32-bit grid positions", who);
     if (g.P + 257 <= 640) {   // one contiguous window of 257 + P positions
         a.a_pieces = (g.P + 257 + 63) / 64; a.seg_slot = g.P; a.seg_delta = 0;
     } else {                  // two 320-slot segments: rows y and y+1
@@ -1628,32 +1798,11 @@ extern "C" int64_t mmlf_packed_filter_h2_bytes(int K, int N)
 {
     const int np = x6_np(N);
     if (np < 0 || K <= 0) return -1;
-    return (int64_t)((K + 7) / 8) * 8 * np * 16 + 16;      // + the scale the packed weights carry
-}
-
-// max |x| of n tensors in one launch: blocks (b, 0..15) reduce sixteenths of tensor b (out zeroed first)
-__global__ __launch_bounds__(256) void amax_many_kernel(const float *const *__restrict__ ptrs,
-                                                        const long long *__restrict__ sizes, float *__restrict__ out)
-{
-    const float *x = ptrs[blockIdx.x];
-    const long long n = sizes[blockIdx.x];
-    float m = 0.f;
-    for (long long i = blockIdx.y * 256ll + threadIdx.x; i < n; i += 256ll * gridDim.y) m = fmaxf(m, fabsf(x[i]));
-    mmlf_amax_update(m, out + blockIdx.x);
-}
-
-extern "C" int mmlf_amax_many(const void *ptrs, const void *sizes, int n, float *out, void *stream)
-{
-    MMLF_CHECK_ARG(ptrs && sizes && out && n > 0, "mmlf_amax_many: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st) != hipSuccess) return mmlf_fail("mmlf_amax_many: memset failed");
-    hipLaunchKernelGGL(amax_many_kernel, dim3(n, 16), dim3(256), 0, st, reinterpret_cast<const float *const *>(ptrs),
-                       reinterpret_cast<const long long *>(sizes), out);
-    return mmlf_launch_status("mmlf_amax_many");
+    return (int64_t)((K + 7) / 8) * 8 * np * 16 + (int64_t)np * 4;      // + 1 / scale of every packed column
 }
 
 extern "C" int mmlf_pack_filter_h2(const float *w, void *packed, int Cout, int Cin, int variant, int dgrad,
-                                   const float *w_amax, void *stream)
+                                   void *stream)
 {
     MMLF_CHECK_ARG(w && packed, "mmlf_pack_filter_h2: null pointer");
     MMLF_CHECK_ARG(variant >= 0 && variant <= 2, "mmlf_pack_filter_h2: bad variant %d", variant);
@@ -1661,21 +1810,10 @@ extern "C" int mmlf_pack_filter_h2(const float *w, void *packed, int Cout, int C
     const int NP = x6_np(N);
     MMLF_CHECK_ARG(NP > 0, "mmlf_pack_filter_h2: N=%d not supported (max 288)", N);
     const int nchunk = (K + 7) / 8;
-    hipStream_t st = (hipStream_t)stream;
+    // the per-column unscale factors sit behind the packed planes
     float *tail = reinterpret_cast<float *>(reinterpret_cast<char *>(packed) + (size_t)nchunk * 8 * NP * 16);
-    // tail[0] = scale; without a caller-supplied max |w|: tail[1] = max |w| (scratch), computed here
-    if (!w_amax) {
-        if (hipMemsetAsync(tail, 0, 16, st) != hipSuccess) return mmlf_fail("mmlf_pack_filter_h2: memset failed");
-        const long long nw = (long long)Cout * Cin * 4;
-        hipLaunchKernelGGL(amax_kernel, dim3((unsigned)((nw + 1023) / 1024 > 256 ? 256 : (nw + 1023) / 1024)),
-                           dim3(256), 0, st, w, nw, tail + 1);
-        w_amax = tail + 1;
-    }
-    const long long total = (long long)nchunk * 32 * NP;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_filter_h2_kernel, dim3(blocks), dim3(256), 0, st, w, (unsigned short *)packed, Cout, Cin,
-                       variant, dgrad, nchunk, NP, w_amax, tail);
+    hipLaunchKernelGGL(pack_filter_h2_kernel, dim3(NP), dim3(256), 0, (hipStream_t)stream, w, (unsigned short *)packed,
+                       Cout, Cin, variant, dgrad, nchunk, NP, tail);
     return mmlf_launch_status("mmlf_pack_filter_h2");
 }
 

@@ -7,7 +7,12 @@
 thread_local char g_mmlf_err[512] = "";
 
 extern "C" const char *mmlf_last_error(void) { return g_mmlf_err; }
-extern "C" int mmlf_abi_version(void) { return 2; }
+extern "C" int mmlf_abi_version(void) { return 3; }
+extern "C" int64_t mmlf_amax_entries(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return -1;
+    return amax_entries(make_grid(B, H, W));
+}
 extern "C" int64_t mmlf_grid_alloc_positions(int B, int H, int W)
 {
     if (B <= 0 || H <= 0 || W <= 0) return -1;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
                 if (V * cg + k < C_store) op[k] = o[k];
         }
     }
-    if (amax) mmlf_amax_update(mx, amax);
+    if (amax) mmlf_amax_update_row(mx, amax, row);      // this workgroup wrote grid row `row`
 }
 
 // NCHW <-> grid
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256) void pack_nchw_kernel(const float *__restrict_
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         *reinterpret_cast<float4 *>(grid + (base + x) * cs + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    if (amax) mmlf_amax_update(mx, amax);
+    if (amax) mmlf_amax_update_row(mx, amax, row);      // this workgroup wrote grid row `row`
 }
 
 __global__ __launch_bounds__(256) void unpack_nchw_kernel(const float *__restrict__ grid, int cs,
@@ -922,21 +927,25 @@ extern "C" int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int
 }
 
 // zero the head and tail slack of a grid buffer in one launch
-__global__ void zero_slack_kernel(float *__restrict__ buf, long long head, long long tail_off, long long tail)
+__global__ void zero_slack_kernel(float *__restrict__ buf, long long head, long long tail_off, long long tail,
+                                  float *__restrict__ amax, long long n_amax)
 {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < head + tail;
-         i += (long long)gridDim.x * blockDim.x)
-        buf[i < head ? i : tail_off + (i - head)] = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < head + tail + n_amax;
+         i += (long long)gridDim.x * blockDim.x) {
+        if (i < head + tail) buf[i < head ? i : tail_off + (i - head)] = 0.f;
+        else amax[i - head - tail] = 0.f;
+    }
 }
 
-extern "C" int mmlf_zero_slack(float *grid, int cs, int B, int H, int W, void *stream)
+extern "C" int mmlf_zero_slack(float *grid, int cs, int B, int H, int W, float *amax, void *stream)
 {
     MMLF_CHECK_ARG(grid && cs > 0 && B > 0 && H > 0 && W > 0, "mmlf_zero_slack: bad argument");
     const Grid g = make_grid(B, H, W);
     const long long head = (long long)(g.P + 1) * cs, tail_off = g.NQ * cs;
     const long long tail = (grid_alloc_positions(g) - g.NQ) * cs;
-    hipLaunchKernelGGL(zero_slack_kernel, dim3(ew_blocks(head + tail)), dim3(256), 0, (hipStream_t)stream, grid, head,
-                       tail_off, tail);
+    const long long n_amax = amax ? amax_entries(g) : 0;
+    hipLaunchKernelGGL(zero_slack_kernel, dim3(ew_blocks(head + tail + n_amax)), dim3(256), 0, (hipStream_t)stream, grid,
+                       head, tail_off, tail, amax, n_amax);
     return mmlf_launch_status("mmlf_zero_slack");
 }
 

@@ -29,24 +29,26 @@ class Geometry:
         self.G = self.P * self.R
         self.NQ = B * self.G
         self.alloc = int(_lib.load().mmlf_grid_alloc_positions(B, H, W))
-        if self.alloc * 288 * 4 >= 2 ** 63 or self.NQ + 600 >= 2 ** 31:
+        self.amax_n = int(_lib.load().mmlf_amax_entries(B, H, W))
+        if self.alloc * 288 * 4 >= 2 ** 63 or self.NQ + 2 * self.P + 600 >= 2 ** 31:
             raise ValueError('batch x image too large for 32-bit grid positions')
-        self._amax_pool, self._amax_used = None, 0
-
-    def _amax_slot(self, device):
-        """A zeroed device scalar: the running max |x| of one grid tensor (its producers raise it by atomic
-        max; the f16-split kernels derive the tensor's power-of-two scale from it)."""
-        if self._amax_pool is None or self._amax_used == self._amax_pool.numel():
-            self._amax_pool, self._amax_used = torch.zeros(256, dtype=torch.float32, device=device), 0
-        self._amax_used += 1
-        return self._amax_pool[self._amax_used - 1:self._amax_used]
 
     def buf(self, cs, device):
-        """Grid buffer with zeroed head/tail slack (the kernels write everything else)."""
+        """Grid buffer with zeroed head/tail slack (the kernels write everything else) and its zeroed amax
+        array: [0] = max |x| of the tensor, [1 + r] = max |x| of grid row r; the tensor's producers raise the
+        entries by atomic max and the f16-split kernels derive their power-of-two operand scales from them."""
         t = torch.empty(self.alloc * cs, dtype=torch.float32, device=device)
-        call('mmlf_zero_slack', ptr(t), cs, self.B, self.H, self.W, _lib.stream_ptr())
-        t.absmax = self._amax_slot(device)
+        t.absmax = torch.empty(self.amax_n, dtype=torch.float32, device=device)
+        call('mmlf_zero_slack', ptr(t), cs, self.B, self.H, self.W, ptr(t.absmax), _lib.stream_ptr())
         return t
+
+    def amax_of(self, t, cs):
+        """amax array of a grid tensor that did not come from buf() (tests, tools): computed with torch ops."""
+        rows = t[:self.NQ * cs].view(self.B * self.R, self.P * cs).abs().amax(1)
+        out = torch.zeros(self.amax_n, dtype=torch.float32, device=t.device)
+        out[0] = rows.max()
+        out[1:1 + rows.numel()] = rows
+        return out
 
 
 class _Workspace:
@@ -68,8 +70,8 @@ class _Workspace:
         self.side = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
         self.partial = torch.empty(2 * 512 * max(BN_BLOCKS, LOSS_BLOCKS) + 8, dtype=torch.float64, device=device)
 
-    def wgrad_ws(self, cin, cout, side=False):
-        n = int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout))
+    def wgrad_ws(self, geo, cin, cout, side=False):
+        n = int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout, geo.B, geo.H, geo.W))
         if n < 0:
             raise RuntimeError(f'wgrad: unsupported channels {cin}->{cout}')
         name = 'wgrad_side' if side else 'wgrad'
@@ -83,8 +85,7 @@ class _Workspace:
 CONV_MODE = os.environ.get('MMLF_CONV_MODE', 'f16x3')
 
 
-def pack_filter(w, variant, dgrad, w_amax=None):
-    """w_amax (f16x3): device scalar max |w|; computed by the pack call when absent."""
+def pack_filter(w, variant, dgrad):
     cout, cin = w.shape[0], w.shape[1]
     K, N = (cout, cin) if dgrad else (cin, cout)
     if CONV_MODE == 'f16x3':
@@ -92,7 +93,7 @@ def pack_filter(w, variant, dgrad, w_amax=None):
         if n < 0:
             raise RuntimeError(f'pack_filter: unsupported channels K={K} N={N}')
         out = torch.empty(n // 4, dtype=torch.float32, device=w.device)
-        call('mmlf_pack_filter_h2', ptr(w), ptr(out), cout, cin, variant, int(dgrad), ptr(w_amax), _lib.stream_ptr())
+        call('mmlf_pack_filter_h2', ptr(w), ptr(out), cout, cin, variant, int(dgrad), _lib.stream_ptr())
         return out
     if CONV_MODE == 'bf16x6':
         n = int(_lib.load().mmlf_packed_filter_split_bytes(cs_of(K), N))
@@ -114,16 +115,20 @@ def pack_filter(w, variant, dgrad, w_amax=None):
 PROFILE = None   # bench.py sets this to a list to time the dominant conv launches with HIP events
 
 
-def _amax_of(t):
-    """The device scalar with max |t| that the f16-split kernels scale by.  Grid tensors made by
-    Geometry.buf carry it (their producers maintain it); for any other tensor it is computed here."""
+def _amax_of(geo, t, cs):
+    """The amax array (tensor and grid-row maxima of |t|) the f16-split kernels scale by.  Grid tensors made
+    by Geometry.buf carry it (their producers maintain it); for any other tensor it is computed here."""
     a = getattr(t, 'absmax', None)
     if a is None:
-        return t.abs().max().reshape(1)
-    if CHECK_ABSMAX:       # test hook: the producers' running maximum must be the tensor's true max |x|
-        true = float(t.abs().max())
-        if float(a) != true:
-            raise AssertionError(f'absmax slot holds {float(a)!r}, tensor max |x| is {true!r}')
+        return geo.amax_of(t, cs)
+    if CHECK_ABSMAX:       # test hook: the producers' running maxima must be the tensor's true maxima
+        true = geo.amax_of(t, cs)
+        exact = geo.P >= 32                 # smaller pitches: rows behind a wave's first get an upper bound
+        bad = (a != true) if exact else (a < true)
+        bad[0] = a[0] != true[0]
+        if bool(bad.any()):
+            k = int(bad.nonzero()[0])
+            raise AssertionError(f'amax entry {k} holds {float(a[k])!r}, true max |x| is {float(true[k])!r}')
     return a
 
 
@@ -137,7 +142,7 @@ def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace
     args = (ptr(x), cs_in, cin, ptr(g), cs_g, cout, g_shift, ptr(gw), ptr(gb), variant, 1, ptr(workspace),
             geo.B, geo.H, geo.W)
     if CONV_MODE == 'f16x3':
-        ax, ag = _amax_of(x), _amax_of(g)
+        ax, ag = _amax_of(geo, x, cs_in), _amax_of(geo, g, cs_g)
         call('mmlf_conv2x2_wgrad_h2', *args, ptr(ax), ptr(ag), _lib.stream_ptr())
     else:
         call('mmlf_conv2x2_wgrad_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad', *args, _lib.stream_ptr())
@@ -154,7 +159,7 @@ def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu
     args = (ptr(x), cs_in, K, ptr(packed), ptr(bias), N, ptr(out) + 4 * out_off, cs_out,
             cs_out if n_store is None else n_store, out_shift, vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref)
     if CONV_MODE == 'f16x3':
-        ax = _amax_of(x)
+        ax = _amax_of(geo, x, cs_in)
         call('mmlf_conv2x2_h2', *args, ptr(ax), ptr(getattr(out, 'absmax', None)), ptr(bn_partial), _lib.stream_ptr())
     else:
         call('mmlf_conv2x2_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2', *args, _lib.stream_ptr())
@@ -175,7 +180,6 @@ class Trunk:
 
     def __init__(self, chs, in_blocks, out_blocks, views, oc, momentum, eps=1e-5):
         self.chs, self.views, self.oc = chs, views, oc
-        self._wabs, self._wtab = {}, None
         self.momentum, self.eps = float(momentum), float(eps)
         cin0 = views * 3
         self.streams = []
@@ -190,29 +194,6 @@ class Trunk:
         if chs % 2 or cs_of(c) != c:
             raise ValueError('native trunk needs an even model_chs with 4*model_chs a multiple of 8')
 
-    # ------------------------------------------------------------------ weights' max |w| (f16x3 scales)
-    def _weight_absmax(self, p):
-        """max |w| of every conv weight in ONE launch (device pointer table cached per parameter set)."""
-        if CONV_MODE != 'f16x3':
-            return {}
-        names = []
-        for _, _, blocks in self.streams:
-            for spec in blocks:
-                names += [f'{spec.prefix}.0.weight', f'{spec.prefix}.2.weight']
-        for spec in self.out_blocks:
-            names += [f'{spec.prefix}.0.weight', f'{spec.prefix}.2.weight']
-        names = list(dict.fromkeys(names))
-        key = tuple(p[n].data_ptr() for n in names)
-        cache = getattr(self, '_wtab', None)
-        if cache is None or cache[0] != key:
-            dev = p[names[0]].device
-            ptrs = torch.tensor(list(key), dtype=torch.int64).to(dev)
-            sizes = torch.tensor([p[n].numel() for n in names], dtype=torch.int64).to(dev)
-            cache = self._wtab = (key, ptrs, sizes)
-        out = torch.empty(len(names), dtype=torch.float32, device=cache[1].device)
-        call('mmlf_amax_many', ptr(cache[1]), ptr(cache[2]), len(names), ptr(out), _lib.stream_ptr())
-        return {n: out[k:k + 1] for k, n in enumerate(names)}
-
     # ------------------------------------------------------------------ forward
     def _block_fwd(self, geo, spec, var, x, cs_x, p, train, rec_list, out=None, cs_out=None, c_off=0):
         """x: grid tensor (extent H,W at (1,1)).  Returns the block output grid tensor."""
@@ -222,7 +203,7 @@ class Trunk:
         cmid, cs_mid = spec.cout, cs_of(spec.cout)
         w1, b1 = p[f'{spec.prefix}.0.weight'], p[f'{spec.prefix}.0.bias']
         w2, b2 = p[f'{spec.prefix}.2.weight'], p[f'{spec.prefix}.2.bias']
-        pk1 = pack_filter(w1, var, False, self._wabs.get(f'{spec.prefix}.0.weight'))
+        pk1 = pack_filter(w1, var, False)
         y = geo.buf(cs_mid, dev)
         conv(geo, x, cs_x, spec.cin, pk1, b1, cmid, y, cs_mid, 0, H + 1, W + 1, True)
         if spec.bn and not train and rec_list is None:   # rec_list is None when nothing is saved for backward
@@ -244,7 +225,7 @@ class Trunk:
                 n_store = C
             conv(geo, y, cs_mid, cmid, pk2, b2f, cmid, out, cs_out, P + 1, H, W, True, n_store=n_store, out_off=c_off)
             return out, cs_out
-        pk2 = pack_filter(w2, var, False, self._wabs.get(f'{spec.prefix}.2.weight'))
+        pk2 = pack_filter(w2, var, False)
         z = geo.buf(cs_mid, dev)
         fused_stats = spec.bn and train and CONV_MODE == 'f16x3'      # statistics from the conv epilogue
         conv(geo, y, cs_mid, cmid, pk2, b2, cmid, z, cs_mid, P + 1, H, W, False,
@@ -294,7 +275,6 @@ class Trunk:
         dev = h.device
         geo = Geometry(B, H, W)
         cin0 = n * c
-        self._wabs = self._weight_absmax(p)
         tape = {'geo': geo, 'streams': [], 'out': []}
         concat = geo.buf(4 * self.chs, dev)
         for s, (key, var, blocks) in enumerate(self.streams):
@@ -349,14 +329,14 @@ class Trunk:
         w1, w2 = p[f'{pre}.0.weight'], p[f'{pre}.2.weight']
         # conv2 (pad 0): weight/bias gradient, then data gradient fused with the ReLU mask of y
         wgrad(geo, y, cs_mid, C, dz, cs_mid, C, P + 1, grads[f'{pre}.2.weight'], grads[f'{pre}.2.bias'], var,
-              ws.wgrad_ws(C, C))
-        pk = pack_filter(w2, var, True, self._wabs.get(f'{pre}.2.weight'))
+              ws.wgrad_ws(geo, C, C))
+        pk = pack_filter(w2, var, True)
         dy = geo.buf(cs_mid, dev)
         conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
         del dz
         # conv1 (pad 1)
         if overlap and need_dx:
-            pk = pack_filter(w1, var, True, self._wabs.get(f'{pre}.0.weight'))
+            pk = pack_filter(w1, var, True)
             dx = geo.buf(cs_x, dev)
             conv(geo, dy, cs_mid, C, pk, None, spec.cin, dx, cs_x, P + 1, H, W, False)
             main = torch.cuda.current_stream()
@@ -364,16 +344,16 @@ class Trunk:
             with torch.cuda.stream(ws.side):
                 ws.side.wait_event(ready)
                 wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'],
-                      var, ws.wgrad_ws(spec.cin, C, side=True))
+                      var, ws.wgrad_ws(geo, spec.cin, C, side=True))
                 done = ws.side.record_event()
             # x and dy are read by the side stream: the caller keeps them alive until the main stream has waited
             # for `done` (no record_stream: deferred reuse makes the caching allocator grow and stall)
             return dx, done, (x, dy)
         wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'], var,
-              ws.wgrad_ws(spec.cin, C))
+              ws.wgrad_ws(geo, spec.cin, C))
         if not need_dx:
             return None
-        pk = pack_filter(w1, var, True, self._wabs.get(f'{pre}.0.weight'))
+        pk = pack_filter(w1, var, True)
         dx = geo.buf(cs_x, dev)
         conv(geo, dy, cs_mid, C, pk, None, spec.cin, dx, cs_x, P + 1, H, W, False)
         return dx
@@ -383,7 +363,6 @@ class Trunk:
         (the caller zeroes them).  on_done(key) is called when every gradient of 'out_net.k' /
         'in_net_id' / 'in_net_hv' has been enqueued (gradient-bucket all-reduce hook)."""
         geo = tape['geo']
-        self._wabs = self._weight_absmax(p)
         dev = grad_output.device
         B, H, W = geo.B, geo.H, geo.W
         cs = cs_of(self.oc)

@@ -159,7 +159,7 @@ def test_conv_backward(oracle, cin, cout, pad, variant, mode, monkeypatch):
     # weight / bias gradient (accumulate on top of a known value)
     tgw = torch.full((cout, cin, 2, 2), 0.5, device=dev)
     tgb = torch.full((cout,), -0.25, device=dev)
-    ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout)), device=dev)
+    ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout, B, H, W)), device=dev)
     engine.wgrad(geo, xg, cs_in, cin, gg, cs_out, cout, fwd_shift, tgw, tgb, variant, ws)
     scale = np.abs(gw).max()
     np.testing.assert_allclose(tgw.cpu().numpy() - 0.5, gw, rtol=1e-4, atol=2e-5 * scale)
@@ -201,12 +201,16 @@ def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
     np.testing.assert_allclose(trv.cpu().numpy(), rv_o, rtol=2e-6)
     y = torch.full((geo.alloc * cs_y,), 7.0, device=dev)
     c_store = C if cs_y != cs else cs
-    amax = torch.zeros(1, device=dev)
+    amax = torch.zeros(geo.amax_n, device=dev)
     call('mmlf_bn_apply_relu', ptr(zg), cs, C, ptr(coef), ptr(coef[C:]), ptr(y), cs_y, c_off, c_store, B, H, W,
          ptr(amax), _lib.stream_ptr())
     full = y.cpu().numpy().reshape(geo.alloc, cs_y)
     got, g = nchw_from_grid(full.reshape(-1), cs_y, cs_y, geo, H, W, 1)
-    assert float(amax) == float(got[:, c_off:c_off + C].max())       # the running max |y| the f16 split scales by
+    # the amax array the f16 split scales by: max |y| of the tensor, then of every grid row
+    assert float(amax[0]) == float(got[:, c_off:c_off + C].max())
+    rows = np.abs(g[..., c_off:c_off + C]).max(axis=(2, 3)).reshape(-1)
+    np.testing.assert_array_equal(amax[1:1 + rows.size].cpu().numpy(), rows)
+    assert not amax[1 + rows.size:].any()
     np.testing.assert_allclose(got[:, c_off:c_off + C], y_ref, rtol=1e-5, atol=2e-6)
     assert (g[:, 0, :, c_off:c_off + C] == 0).all() and (g[:, :, 0, c_off:c_off + C] == 0).all()
     other = np.delete(full[:geo.NQ], np.s_[c_off:c_off + c_store], axis=1)
@@ -235,7 +239,7 @@ def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
     amax.zero_()
     call('mmlf_bn_bwd_apply', ptr(gyg), cs_y, c_off, ptr(zg), cs, C, ptr(coef), ptr(coef[C:]), ptr(coef[2 * C:]),
          ptr(k), ptr(dz), cs, B, H, W, ptr(amax), _lib.stream_ptr())
-    assert float(amax) == float(dz[:geo.NQ * cs].abs().max())
+    assert torch.equal(amax, geo.amax_of(dz, cs))
     np.testing.assert_allclose(dgam.cpu().numpy() - 1, gg_ref, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(dbet.cpu().numpy() - 1, gb_ref, rtol=1e-4, atol=1e-4)
     got, g = nchw_from_grid(dz.cpu().numpy(), cs, C, geo, H, W, 1)
@@ -253,9 +257,10 @@ def test_pack_unpack_roundtrip():
     x = rs.uniform(-1, 1, (B, C, H, W)).astype(np.float32)
     g = torch.full((geo.alloc * 32,), float('nan'), device=dev)
     g[geo.NQ * 32:] = 0
-    amax = torch.zeros(1, device=dev)
+    amax = torch.zeros(geo.amax_n, device=dev)
     call('mmlf_pack_nchw', ptr(torch.from_numpy(x).to(dev)), C, ptr(g), 32, B, H, W, ptr(amax), _lib.stream_ptr())
-    assert float(amax) == float(np.abs(x).max())
+    assert float(amax[0]) == float(np.abs(x).max())
+    assert torch.equal(amax, geo.amax_of(g, 32))
     np.testing.assert_array_equal(g.cpu().numpy(), grid_from_nchw(x, 32, geo))
     back = torch.empty((B, C, H, W), device=dev)
     call('mmlf_unpack_nchw', ptr(g), 32, ptr(back), C, B, H, W, _lib.stream_ptr())
@@ -312,7 +317,7 @@ def test_full_size_adjoint_identities(cin, cout, pad, mode, monkeypatch):
                 ih, iw, False)
     gw = torch.zeros_like(w)
     gb = torch.zeros(cout, device=dev)
-    ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout)), device=dev)
+    ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout, B, H, W)), device=dev)
     engine.wgrad(geo, x, cs_in, cin, g, cs_out, cout, fwd_shift, gw, gb, 0, ws)
     lhs = torch.dot(out.double(), g.double())
     via_x = torch.dot(x.double(), dx.double()) + torch.dot(bias.double(), gb.double())
@@ -373,7 +378,7 @@ def test_fused_batchnorm_statistics_match_the_two_pass_form(cin, cout):
     from mmlf_amd import engine, _lib
     from mmlf_amd._lib import call, ptr
     dev = _dev()
-    B, H, W = 6, 23, 19
+    B, H, W = 6, 23, 31
     geo = engine.Geometry(B, H, W)
     cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
     gen = torch.Generator(device=dev).manual_seed(cin)
@@ -383,8 +388,8 @@ def test_fused_batchnorm_statistics_match_the_two_pass_form(cin, cout):
     bias = torch.rand(cout, device=dev, generator=gen) - 0.5
     n = int(_lib.load().mmlf_packed_filter_h2_bytes(cs_in, cout))
     pk = torch.empty(n // 4, device=dev)
-    call('mmlf_pack_filter_h2', ptr(w), ptr(pk), cout, cin, 0, 0, None, _lib.stream_ptr())
-    amax = x.abs().max().reshape(1)
+    call('mmlf_pack_filter_h2', ptr(w), ptr(pk), cout, cin, 0, 0, _lib.stream_ptr())
+    amax = geo.amax_of(x, cs_in)
     z = geo.buf(cs_out, dev)
     nblk = int(_lib.load().mmlf_conv2x2_blocks(cout, B, H, W))
     partial = torch.full((nblk * 2 * cout + 8,), float('nan'), dtype=torch.float64, device=dev)
@@ -405,23 +410,21 @@ def test_fused_batchnorm_statistics_match_the_two_pass_form(cin, cout):
         out[mode] = (c.cpu().numpy(), rm.cpu().numpy(), rv.cpu().numpy())
     for a, b in zip(out['fused'], out['two_pass']):
         np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7)
-    assert float(z.absmax) == float(z.abs().max())
+    assert torch.equal(z.absmax, geo.amax_of(z, cs_out))      # the conv epilogue's tensor and grid-row maxima (P >= 32: exact)
 
 
-def test_weight_absmax_table_and_slack_zeroing():
+def test_slack_and_amax_zeroing():
     from mmlf_amd import engine, _lib
     from mmlf_amd._lib import call, ptr
     dev = _dev()
-    ts = [torch.randn(n, device=dev) * s for n, s in ((313600, 0.03), (7, 5.0), (19600, 1e-6), (1, 0.0))]
-    ptrs = torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64).to(dev)
-    sizes = torch.tensor([t.numel() for t in ts], dtype=torch.int64).to(dev)
-    out = torch.full((len(ts),), -1.0, device=dev)
-    call('mmlf_amax_many', ptr(ptrs), ptr(sizes), len(ts), ptr(out), _lib.stream_ptr())
-    assert out.tolist() == [float(t.abs().max()) for t in ts]
     B, H, W, cs = 3, 5, 7, 8
     geo = engine.Geometry(B, H, W)
+    assert geo.amax_n >= 1 + B * geo.R
     buf = torch.full((geo.alloc * cs,), 3.0, device=dev)
-    call('mmlf_zero_slack', ptr(buf), cs, B, H, W, _lib.stream_ptr())
+    amax = torch.full((geo.amax_n + 3,), 5.0, device=dev)
+    call('mmlf_zero_slack', ptr(buf), cs, B, H, W, ptr(amax), _lib.stream_ptr())
     v = buf.cpu().numpy()
     assert not v[:(geo.P + 1) * cs].any() and not v[geo.NQ * cs:].any()
     assert (v[(geo.P + 1) * cs:geo.NQ * cs] == 3.0).all()
+    assert not amax[:geo.amax_n].any() and (amax[geo.amax_n:] == 5.0).all()
+    call('mmlf_zero_slack', ptr(buf), cs, B, H, W, None, _lib.stream_ptr())      # the amax array is optional

@@ -77,6 +77,6 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mmlf_abi_version() == 2
+    assert lib.mmlf_abi_version() == 3
     lib.mmlf_grid_alloc_positions.restype = ctypes.c_int64
     assert lib.mmlf_grid_alloc_positions(2, 96, 96) >= 2 * 98 * 98 + 99

@@ -14,7 +14,7 @@ def bench(cin, cout, pad, reps=10):
         x.zero_(); w.zero_()
     b = torch.randn(cout, device=dev)
     pk = engine.pack_filter(w, 0, False)
-    x.absmax = x.abs().max().reshape(1)
+    x.absmax = geo.amax_of(x, cs_in)
     out = torch.zeros(geo.alloc * cs_out, device=dev)
     shift, vh, vw = (0, H + 1, W + 1) if pad else (geo.P + 1, H, W)
     for _ in range(2):
@@ -31,8 +31,8 @@ def bench(cin, cout, pad, reps=10):
     # wgrad
     g = torch.randn(geo.alloc * cs_out, device=dev)
     gw = torch.zeros(cout, cin, 2, 2, device=dev); gb = torch.zeros(cout, device=dev)
-    ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout)), device=dev)
-    x.absmax, g.absmax = x.abs().max().reshape(1), g.abs().max().reshape(1)     # what the producers maintain
+    ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout, B, H, W)), device=dev)
+    x.absmax, g.absmax = geo.amax_of(x, cs_in), geo.amax_of(g, cs_out)     # what the producers maintain
     for _ in range(2):
         engine.wgrad(geo, x, cs_in, cin, g, cs_out, cout, shift, gw, gb, 0, ws)
     torch.cuda.synchronize()

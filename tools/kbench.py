@@ -1,0 +1,73 @@
+"""Kernel micro-benchmark for A/B runs on one box: the dominant launches of a bs=512 step, each timed with HIP
+events, median over reps.  MMLF_HIP_LIB selects the library build.   python tools/kbench.py [B] [reps] [tag]"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.getcwd())
+from mmlf_amd import engine, _lib
+from mmlf_amd._lib import call, ptr
+dev = torch.device('cuda:0')
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+TAG = sys.argv[3] if len(sys.argv) > 3 else os.environ.get('MMLF_HIP_LIB', 'default')
+H = W = 96
+geo = engine.Geometry(B, H, W)
+NEW = hasattr(geo, 'amax_n')
+
+
+def amax_for(t, cs):
+    return geo.amax_of(t, cs) if NEW else t.abs().max().reshape(1)
+
+
+def timeit(fn):
+    fn(); fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(REPS):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def grid_rand(cs, c, h, w, off, relu=False):
+    t = geo.buf(cs, dev)
+    v = t[:geo.NQ * cs].view(B, geo.R, geo.P, cs)
+    v.zero_()
+    r = torch.randn((B, h, w, c), device=dev)
+    v[:, off:off + h, off:off + w, :c] = r.clamp_(min=0) if relu else r
+    t.absmax = amax_for(t, cs)
+    return t
+
+
+def run(cin, cout):
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    w = torch.randn(cout, cin, 2, 2, device=dev) * 0.03
+    b = torch.randn(cout, device=dev) * 0.1
+    pk, pkd = engine.pack_filter(w, 0, False), engine.pack_filter(w, 0, True)
+    x = grid_rand(cs_in, cin, H, W, 1, relu=True)          # block input (extent H,W at (1,1))
+    y = grid_rand(cs_out, cout, H + 1, W + 1, 0, relu=True)  # conv1 output
+    out1, out0 = geo.buf(cs_out, dev), geo.buf(cs_out, dev)
+    ws = engine._Workspace.get(dev)
+    fl1 = 2.0 * B * (H + 1) * (W + 1) * cout * 4 * cin
+    fl0 = 2.0 * B * H * W * cout * 4 * cin
+    res = {}
+    res['fwd_p1'] = (timeit(lambda: engine.conv(geo, x, cs_in, cin, pk, b, cout, out1, cs_out, 0, H + 1, W + 1, True)), fl1)
+    res['fwd_p0_stats'] = (timeit(lambda: engine.conv(geo, y, cs_out, cout, pk, b, cout, out0, cs_out, geo.P + 1, H, W, False,
+                                                        bn_partial=ws.partial)), fl0)
+    g0 = grid_rand(cs_out, cout, H, W, 1)                     # dz
+    res['dgrad_p0_ref'] = (timeit(lambda: engine.conv(geo, g0, cs_out, cout, pkd, None, cin, out1, cs_in, 0, H + 1, W + 1, False,
+                                                       ref=y, cs_ref=cs_out)), fl1)
+    g1 = grid_rand(cs_out, cout, H + 1, W + 1, 0)             # dy
+    res['dgrad_p1'] = (timeit(lambda: engine.conv(geo, g1, cs_out, cout, pkd, None, cin, out0, cs_in, geo.P + 1, H, W, False)), fl0)
+    gw, gb = torch.zeros_like(w), torch.zeros(cout, device=dev)
+    wsb = ws.wgrad_ws(geo, cin, cout) if NEW else ws.wgrad_ws(cin, cout)
+    res['wgrad_p1'] = (timeit(lambda: engine.wgrad(geo, x, cs_in, cin, g1, cs_out, cout, 0, gw, gb, 0, wsb)), fl1)
+    res['wgrad_p0'] = (timeit(lambda: engine.wgrad(geo, y, cs_out, cout, g0, cs_out, cout, geo.P + 1, gw, gb, 0, wsb)), fl0)
+    for k, ((med, mn), fl) in res.items():
+        print(f'{TAG} {cin}->{cout} B={B} {k:14s} median {med:8.3f} ms  min {mn:8.3f} ms  {fl / med / 1e9:7.1f} TFLOP/s', flush=True)
+
+
+run(280, 280)
+if not os.environ.get("KBENCH_ONLY280"): run(70, 70)
