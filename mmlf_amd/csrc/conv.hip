@@ -182,15 +182,34 @@ __host__ __device__ __forceinline__ float pow2_scale_for(float amax)
     __builtin_memcpy(&r, &u, 4);
     return r;
 }
+// SCALAR: plain (unpacked) f32 VALU for code that runs BESIDE MFMAs, where a v_pk_*_f32 costs more issue time
+// than the two scalar instructions it replaces (wgrad staging, the pipelined conv: +2 %); at a chunk head with
+// no MFMA in flight the packed form is the faster one (conv4tap_x6s_kernel: scalar there costs 5 %).
+template <bool SCALAR = false>
 __device__ __forceinline__ void split2_pair_f16(float a, float b, float s, unsigned &h, unsigned &l)
 {
-    const f32x2_t v = {a * s, b * s};
-    const f16x2_t hh = __builtin_convertvector(v, f16x2_t);
-    const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
-    const f32x2_t r = {v[0] - back[0], v[1] - back[1]};
-    const f16x2_t ll = __builtin_convertvector(r, f16x2_t);
-    h = __builtin_bit_cast(unsigned, hh);
-    l = __builtin_bit_cast(unsigned, ll);
+    if constexpr (SCALAR) {
+        float va, vb, ra, rb;
+        asm("v_mul_f32 %0, %1, %2" : "=v"(va) : "s"(s), "v"(a));
+        asm("v_mul_f32 %0, %1, %2" : "=v"(vb) : "s"(s), "v"(b));
+        const f32x2_t v0 = {va, vb};
+        const f16x2_t hh0 = __builtin_convertvector(v0, f16x2_t);
+        const f32x2_t back0 = __builtin_convertvector(hh0, f32x2_t);
+        asm("v_sub_f32 %0, %1, %2" : "=v"(ra) : "v"(va), "v"(back0[0]));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(rb) : "v"(vb), "v"(back0[1]));
+        const f32x2_t r0 = {ra, rb};
+        const f16x2_t ll0 = __builtin_convertvector(r0, f16x2_t);
+        h = __builtin_bit_cast(unsigned, hh0);
+        l = __builtin_bit_cast(unsigned, ll0);
+    } else {
+        const f32x2_t v = {a * s, b * s};
+        const f16x2_t hh = __builtin_convertvector(v, f16x2_t);
+        const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
+        const f32x2_t r = {v[0] - back[0], v[1] - back[1]};
+        const f16x2_t ll = __builtin_convertvector(r, f16x2_t);
+        h = __builtin_bit_cast(unsigned, hh);
+        l = __builtin_bit_cast(unsigned, ll);
+    }
 }
 // f16-split filter packing: [chunk][plane(2)][tap(4)][NP][8 f16] of w * scale[n], one workgroup per packed
 // column n (= output channel of the launch).  Every column carries its own power-of-two scale (its max |w|
@@ -659,6 +678,8 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
 #undef X6_DMA_WAIT
 }
 
+
+
 // 512 threads = 8 waves; tile = 256 positions x NT*32 output channels; wave w owns positions
 // [32w, 32w+32) x all channels (NT accumulator tiles of 32x32).  K is walked in chunks of 8 input
 // channels x 4 taps, double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4: no
@@ -955,8 +976,8 @@ __device__ __forceinline__ void split_store4_pl(float4 v, float scale, char *p0,
         split_store4(v, p0, plane_stride_bytes);
     } else {
         unsigned h0, l0, h1, l1;
-        split2_pair_f16(v.x, v.y, scale, h0, l0);
-        split2_pair_f16(v.z, v.w, scale, h1, l1);
+        split2_pair_f16<true>(v.x, v.y, scale, h0, l0);
+        split2_pair_f16<true>(v.z, v.w, scale, h1, l1);
         *reinterpret_cast<uint2 *>(p0) = make_uint2(h0, h1);
         *reinterpret_cast<uint2 *>(p0 + plane_stride_bytes) = make_uint2(l0, l1);
     }
