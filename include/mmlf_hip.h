@@ -200,6 +200,22 @@ int mmlf_loss_fwd_bwd(int kind, const float *output_nchw, int oc, const float *g
                       double *scratch, int nblocks, const double *den_override, int B, int H, int W,
                       void *stream);
 
+/* Multimodal and padded training losses (value + gradient w.r.t. the raw out_net output), reference loss.py:
+ * kind 3: MultiMaskedL1Loss (:80-103)   4: ImprovedMultiUncertaintyL1Loss (:336-372)
+ *      5: MaskedCrossEntropy (:146-160) on the target mpi_to_weights(mpi) (mmlf/utils/dl.py:134-157)
+ *      6: ImprovedUncertaintyL1Loss WITH mask_padding (:264-294; --train_loss_padding, train/cli.py:217-222)
+ * target: kinds 3-5 the multi-plane tensor mpi (B, P, 5, H, W) ([:, :, 3] alpha, [:, :, 4] disparity); kind 6
+ * gt (B, H, W) with mask_padding int32 (B, H, W).  scratch: mmlf_loss_multi_scratch_doubles(nblocks) doubles.
+ * aux_override (nullable, device double[2]): the whole-batch sums kinds 4 / 6 normalise by (sum of the total
+ * alpha and count of surface-less pixels; count of in-range pixels) -- the all-reduced ones under data
+ * parallelism, since the reference evaluates the loss on the gathered batch. */
+int64_t mmlf_loss_multi_scratch_doubles(int nblocks);
+int mmlf_loss_multi_fwd_bwd(int kind, const float *output_nchw, int oc, const float *target, int P,
+                            const int32_t *mask, const int32_t *mask_padding, const float *grid_torch,
+                            double half_step, float *loss_out, float *grad_nchw, double *scratch, int nblocks,
+                            const double *den_override, const double *aux_override, int B, int H, int W,
+                            void *stream);
+
 /* torch.optim.Adam step with default hyper-parameters (train/cli.py:117-118,258) on a flat buffer.
  * g is multiplied by grad_scale first (1/world_size after the RCCL sum all-reduce). */
 int mmlf_adam_step(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1,

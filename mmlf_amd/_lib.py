@@ -48,6 +48,8 @@ SIGNATURES = {
     'mmlf_head_upr': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_head_dpp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_loss_fwd_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    'mmlf_loss_multi_scratch_doubles': (_i64, [_i]),
+    'mmlf_loss_multi_fwd_bwd': (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     'mmlf_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i64, _d, _vp]),
     'mmlf_shift_views': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_lmm_to_discrete': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),

@@ -496,6 +496,198 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(int kind, const float *_
 }
 
 // ---------------------------------------------------------------------------------------------
+// multimodal / padded training losses (reference loss.py:80-103, 336-372, 264-294 with mask_padding;
+// dl.py:134-157 mpi_to_weights feeding loss.py:146-160).  target = mpi (B,P,5,H,W): [:, :, 3] alpha,
+// [:, :, 4] disparity -- or gt (B,H,W) for the padded single-mode loss.  Two of them need whole-batch sums
+// first (aux[0], aux[1]): kind 4 the sum of the total alpha and the number of pixels without a surface,
+// kind 6 the number of in-range pixels.
+// ---------------------------------------------------------------------------------------------
+enum { LOSS_MULTI_L1 = 3, LOSS_MULTI_UPR = 4, LOSS_MULTI_CE = 5, LOSS_UPR_PADDED = 6 };
+
+struct MultiLossArgs {
+    const float *out;            // (B, oc, H, W)
+    const float *target;         // mpi (B, P, 5, H, W) | gt (B, H, W)
+    const int32_t *mask, *mask_padding;
+    const float *grid;           // kind 5: torch.linspace bin centres
+    double *scratch;             // [0] 1/den [1] count [2 + 2b] block partials ... [2 + 2*nblocks + {0,1}] aux sums
+    float *grad;
+    const double *den_override, *aux_override;
+    float half_step;
+    int kind, oc, P, HW, nblocks;
+    long long total;             // B*H*W
+};
+
+__device__ __forceinline__ void block_sum2(double &a, double &b)
+{
+    __shared__ double r0[256], r1[256];
+    r0[threadIdx.x] = a; r1[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    a = r0[0]; b = r1[0];
+}
+
+// pass 0: whole-batch sums the per-pixel loss depends on (kinds 4 and 6), per-block partials
+__global__ __launch_bounds__(256) void loss_multi_aux_kernel(MultiLossArgs a)
+{
+    double s0 = 0, s1 = 0;
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < a.total; idx += 256ll * gridDim.x) {
+        if (a.kind == LOSS_MULTI_UPR) {
+            const long long b = idx / a.HW;
+            const int p = (int)(idx - b * a.HW);
+            float tot = 0.f;
+            for (int k = 0; k < a.P; ++k) tot = __fadd_rn(tot, a.target[((b * a.P + k) * 5 + 3) * a.HW + p]);
+            s0 += tot;
+            s1 += tot < 0.01f ? 1.0 : 0.0;
+        } else {
+            s0 += a.mask_padding[idx];
+        }
+    }
+    block_sum2(s0, s1);
+    if (threadIdx.x == 0) {
+        a.scratch[2 + 2 * a.nblocks + 2 + 2 * blockIdx.x] = s0;
+        a.scratch[2 + 2 * a.nblocks + 3 + 2 * blockIdx.x] = s1;
+    }
+}
+__global__ void loss_multi_aux_finalize_kernel(MultiLossArgs a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s0 = 0, s1 = 0;
+    if (a.aux_override) { s0 = a.aux_override[0]; s1 = a.aux_override[1]; }
+    else for (int b = 0; b < a.nblocks; ++b) {
+        s0 += a.scratch[2 + 2 * a.nblocks + 2 + 2 * b];
+        s1 += a.scratch[2 + 2 * a.nblocks + 3 + 2 * b];
+    }
+    a.scratch[2 + 2 * a.nblocks] = s0;
+    a.scratch[2 + 2 * a.nblocks + 1] = s1;
+}
+
+// per-pixel loss and (grad != null) its derivative w.r.t. mean / logvar; CE handled apart
+struct PixelLoss { float l, dm, dlv; };
+__device__ __forceinline__ PixelLoss multi_pixel(const MultiLossArgs &a, long long idx, float f0, float f1)
+{
+    const long long b = idx / a.HW;
+    const int p = (int)(idx - b * a.HW);
+    const float m = a.out[(b * a.oc) * a.HW + p];
+    PixelLoss r = {0.f, 0.f, 0.f};
+    if (a.kind == LOSS_MULTI_L1) {
+        for (int k = 0; k < a.P; ++k) {
+            const float w = a.target[((b * a.P + k) * 5 + 3) * a.HW + p], t = a.target[((b * a.P + k) * 5 + 4) * a.HW + p];
+            const float d = __fsub_rn(m, t);
+            r.l = __fadd_rn(r.l, __fmul_rn(fabsf(d), w));
+            r.dm = __fadd_rn(r.dm, __fmul_rn(sgnf(d), w));
+        }
+    } else if (a.kind == LOSS_MULTI_UPR) {         // f0 = mean total alpha, f1 = n / #(pixels without a surface)
+        const float lv = a.out[(b * a.oc + 1) * a.HW + p], e = expf(-lv);
+        float tot = 0.f, acc = 0.f, gm = 0.f, glv = 0.f;
+        for (int k = 0; k < a.P; ++k) {
+            const float w = a.target[((b * a.P + k) * 5 + 3) * a.HW + p], t = a.target[((b * a.P + k) * 5 + 4) * a.HW + p];
+            const float d = __fsub_rn(m, t);
+            acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(__fmul_rn(e, fabsf(d)), lv), w));
+            gm = __fadd_rn(gm, __fmul_rn(__fmul_rn(e, sgnf(d)), w));
+            glv = __fadd_rn(glv, __fmul_rn(__fsub_rn(1.f, __fmul_rn(e, fabsf(d))), w));
+            tot = __fadd_rn(tot, w);
+        }
+        const float oor = tot < 0.01f ? 1.f : 0.f;
+        const float l_oor = __fmul_rn(__fmul_rn(-lv, oor), f1);        // 0 * inf = NaN when no pixel lacks a surface, as in the reference
+        r.l = __fdiv_rn(__fadd_rn(__fdiv_rn(acc, f0), l_oor), 2.f);
+        r.dm = __fdiv_rn(__fdiv_rn(gm, f0), 2.f);
+        r.dlv = __fdiv_rn(__fsub_rn(__fdiv_rn(glv, f0), __fmul_rn(oor, f1)), 2.f);
+    } else {                                        // LOSS_UPR_PADDED: f0 = n / #in-range, f1 = n / #out-of-range (1 if none)
+        const float lv = a.out[(b * a.oc + 1) * a.HW + p], e = expf(-lv);
+        const float d = __fsub_rn(m, a.target[idx]);
+        const float mp = (float)a.mask_padding[idx], oor = 1.f - mp;
+        const float l_in = __fmul_rn(__fmul_rn(__fadd_rn(__fmul_rn(e, fabsf(d)), lv), mp), f0);
+        const float l_oor = __fmul_rn(__fmul_rn(-lv, oor), f1);
+        r.l = __fdiv_rn(__fadd_rn(l_in, l_oor), 2.f);
+        r.dm = __fdiv_rn(__fmul_rn(__fmul_rn(__fmul_rn(e, sgnf(d)), mp), f0), 2.f);
+        r.dlv = __fdiv_rn(__fsub_rn(__fmul_rn(__fmul_rn(__fsub_rn(1.f, __fmul_rn(e, fabsf(d))), mp), f0), __fmul_rn(oor, f1)), 2.f);
+    }
+    return r;
+}
+__device__ __forceinline__ void multi_factors(const MultiLossArgs &a, float &f0, float &f1)
+{
+    const double s0 = a.scratch[2 + 2 * a.nblocks], s1 = a.scratch[2 + 2 * a.nblocks + 1], n = (double)a.total;
+    f0 = f1 = 1.f;
+    if (a.kind == LOSS_MULTI_UPR) { f0 = (float)(s0 / n); f1 = (float)n / (float)s1; }
+    else if (a.kind == LOSS_UPR_PADDED) {
+        if (s0 > 0) f0 = (float)n / (float)s0;
+        if (n - s0 > 0) f1 = (float)n / (float)(n - s0);
+    }
+}
+// MaskedCrossEntropy on the weighted more-hot target mpi_to_weights(mpi): t_k = sum_p [|grid_k - d_p| < step/2] * alpha_p
+__device__ __forceinline__ float multi_ce_target(const MultiLossArgs &a, long long b, int p, int k)
+{
+    float t = 0.f;
+    for (int q = 0; q < a.P; ++q) {
+        const float w = a.target[((b * a.P + q) * 5 + 3) * a.HW + p], d = a.target[((b * a.P + q) * 5 + 4) * a.HW + p];
+        t = __fadd_rn(t, fabsf(__fsub_rn(a.grid[k], d)) < a.half_step ? w : 0.f);
+    }
+    return t;
+}
+__device__ __forceinline__ float multi_ce_pixel(const MultiLossArgs &a, long long b, int p, float *z_out)
+{
+    const float *s = a.out + b * a.oc * a.HW + p;
+    float dot = 0.f, z = 0.f;
+    for (int k = 0; k < a.oc; ++k) {
+        const float v = fmaxf(s[(size_t)k * a.HW], 0.f);
+        dot = __fadd_rn(dot, __fmul_rn(v, multi_ce_target(a, b, p, k)));
+        z = __fadd_rn(z, expf(v));
+    }
+    *z_out = z;
+    return -logf(__fdiv_rn(expf(dot), z));
+}
+
+__global__ __launch_bounds__(256) void loss_multi_partial_kernel(MultiLossArgs a)
+{
+    float f0, f1;
+    multi_factors(a, f0, f1);
+    double cnt = 0, sum = 0;
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < a.total; idx += 256ll * gridDim.x) {
+        const int mk = a.mask[idx];
+        cnt += mk;
+        float l;
+        if (a.kind == LOSS_MULTI_CE) {
+            float z;
+            const long long b = idx / a.HW;
+            l = multi_ce_pixel(a, b, (int)(idx - b * a.HW), &z);
+        } else {
+            l = multi_pixel(a, idx, f0, f1).l;
+        }
+        sum += (double)(l * (float)mk);
+    }
+    block_sum2(cnt, sum);
+    if (threadIdx.x == 0) { a.scratch[2 + 2 * blockIdx.x] = cnt; a.scratch[3 + 2 * blockIdx.x] = sum; }
+}
+
+__global__ __launch_bounds__(256) void loss_multi_grad_kernel(MultiLossArgs a)
+{
+    float f0, f1;
+    multi_factors(a, f0, f1);
+    const float inv = (float)a.scratch[0];
+    for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < a.total; idx += 256ll * gridDim.x) {
+        const long long b = idx / a.HW;
+        const int p = (int)(idx - b * a.HW);
+        const float mk = (float)a.mask[idx] * inv;
+        if (a.kind == LOSS_MULTI_CE) {
+            float z;
+            multi_ce_pixel(a, b, p, &z);
+            const float *s = a.out + b * a.oc * a.HW + p;
+            for (int k = 0; k < a.oc; ++k) {
+                const float raw = s[(size_t)k * a.HW];
+                a.grad[(b * a.oc + k) * a.HW + p] = raw > 0.f ? (expf(raw) / z - multi_ce_target(a, b, p, k)) * mk : 0.f;
+            }
+        } else {
+            const PixelLoss r = multi_pixel(a, idx, f0, f1);
+            a.grad[(b * a.oc) * a.HW + p] = r.dm * mk;
+            if (a.kind != LOSS_MULTI_L1) a.grad[(b * a.oc + 1) * a.HW + p] = r.dlv * mk;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam defaults: no weight decay, no amsgrad)
 // ---------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
@@ -997,6 +1189,37 @@ extern "C" int mmlf_loss_fwd_bwd(int kind, const float *output, int oc, const fl
         hipLaunchKernelGGL(loss_grad_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, kind, output, oc, gt, mask,
                            grid_torch, (float)half_step, scratch, grad, H * W, total);
     return mmlf_launch_status("mmlf_loss_fwd_bwd");
+}
+
+extern "C" int64_t mmlf_loss_multi_scratch_doubles(int nblocks) { return nblocks > 0 ? 4ll * nblocks + 4 : -1; }
+
+extern "C" int mmlf_loss_multi_fwd_bwd(int kind, const float *output, int oc, const float *target, int P,
+                                       const int32_t *mask, const int32_t *mask_padding, const float *grid_torch,
+                                       double half_step, float *loss_out, float *grad, double *scratch, int nblocks,
+                                       const double *den_override, const double *aux_override, int B, int H, int W,
+                                       void *stream)
+{
+    MMLF_CHECK_ARG(kind >= LOSS_MULTI_L1 && kind <= LOSS_UPR_PADDED, "mmlf_loss_multi_fwd_bwd: kind=%d", kind);
+    MMLF_CHECK_ARG(output && target && mask && loss_out && scratch, "mmlf_loss_multi_fwd_bwd: null pointer");
+    MMLF_CHECK_ARG(kind == LOSS_UPR_PADDED ? mask_padding != nullptr : P >= 1, "mmlf_loss_multi_fwd_bwd: P=%d / mask_padding", P);
+    MMLF_CHECK_ARG((kind == LOSS_MULTI_L1 && oc >= 1) || (kind == LOSS_MULTI_CE && grid_torch && oc >= 1) ||
+                       ((kind == LOSS_MULTI_UPR || kind == LOSS_UPR_PADDED) && oc >= 2),
+                   "mmlf_loss_multi_fwd_bwd: oc=%d for kind=%d", oc, kind);
+    MMLF_CHECK_ARG(nblocks > 0 && nblocks <= 4096 && B > 0 && H > 0 && W > 0, "mmlf_loss_multi_fwd_bwd: nblocks=%d", nblocks);
+    MultiLossArgs a;
+    a.out = output; a.target = target; a.mask = mask; a.mask_padding = mask_padding; a.grid = grid_torch;
+    a.scratch = scratch; a.grad = grad; a.den_override = den_override; a.aux_override = aux_override;
+    a.half_step = (float)half_step; a.kind = kind; a.oc = oc; a.P = P; a.HW = H * W; a.nblocks = nblocks;
+    a.total = (long long)B * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == LOSS_MULTI_UPR || kind == LOSS_UPR_PADDED) {
+        if (!aux_override) hipLaunchKernelGGL(loss_multi_aux_kernel, dim3(nblocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(loss_multi_aux_finalize_kernel, dim3(1), dim3(64), 0, st, a);
+    }
+    hipLaunchKernelGGL(loss_multi_partial_kernel, dim3(nblocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, scratch, nblocks, loss_out, den_override);
+    if (grad) hipLaunchKernelGGL(loss_multi_grad_kernel, dim3(ew_blocks(a.total)), dim3(256), 0, st, a);
+    return mmlf_launch_status("mmlf_loss_multi_fwd_bwd");
 }
 
 extern "C" int mmlf_adam_step(float *p, const float *g, float *m, float *v, int64_t n, double lr, double beta1,

@@ -254,6 +254,12 @@ class Trunk:
         else:
             call('mmlf_bn_coeffs_eval', ptr(g), ptr(bt), ptr(rm), ptr(rv), self.eps, ptr(scale), ptr(shift), C,
                  _lib.stream_ptr())
+            if rec_list is not None:
+                # eval-mode BatchNorm under autograd (reference train/cli.py:227-230, --train_eval_mode): the
+                # statistics are constants, so backward is dz = g * gamma * invstd with the RUNNING statistics
+                smean.copy_(rm)
+                sinv.copy_(torch.rsqrt(rv.double() + self.eps).float())
+                rec['eval'] = True
         if out is None:
             cs_out, c_off = cs_mid, 0
             out = geo.buf(cs_out, dev)
@@ -318,6 +324,8 @@ class Trunk:
             call('mmlf_bn_bwd_reduce', ptr(gy), cs_gy, c_off, ptr(z), cs_mid, C, ptr(rec['scale']), ptr(rec['shift']),
                  ptr(p[f'{pre}.3.weight']), ptr(rec['smean']), ptr(rec['sinv']), ptr(grads[f'{pre}.3.weight']),
                  ptr(grads[f'{pre}.3.bias']), 1, ptr(coef), ptr(ws.partial), BN_BLOCKS, B, H, W, sp())
+            if rec.get('eval'):
+                coef[C:].zero_()            # no batch-statistics terms: dz = k1 * g (dgamma / dbeta sums are the same)
             dz = geo.buf(cs_mid, dev)
             call('mmlf_bn_bwd_apply', ptr(gy), cs_gy, c_off, ptr(z), cs_mid, C, ptr(rec['scale']), ptr(rec['shift']),
                  ptr(rec['smean']), ptr(coef), ptr(dz), cs_mid, B, H, W, ptr(dz.absmax), sp())

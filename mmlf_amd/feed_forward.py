@@ -41,27 +41,27 @@ class _TrunkFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, train, save, h, v, i, d, *params):
-        p = module._tensor_dict()
+        p = module._tensor_dict()                       # buffers; parameters as passed (a replica's per-device copies)
+        p.update(zip(module._param_names, (t.detach() for t in params)))
         with torch.no_grad():
             out, tape = module._trunk.forward(p, [h, v, i, d], train, save)
-        ctx.module, ctx.tape = module, tape
+        ctx.module, ctx.tape, ctx.p = module, tape, (p if save else None)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        module, tape = ctx.module, ctx.tape
+        module, tape, p = ctx.module, ctx.tape, ctx.p
         if tape is None:
             raise RuntimeError('FeedForward: backward through a forward that saved nothing')
-        ctx.tape = None
+        ctx.tape = ctx.p = None
         names = module._param_names
-        p = module._tensor_dict()
         sizes = [p[n].numel() for n in names]
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=gout.device)
         grads, o = {}, 0
         for n, sz in zip(names, sizes):
             grads[n] = flat[o:o + sz].view_as(p[n])
             o += sz
-        with torch.no_grad():
+        with torch.no_grad(), torch.cuda.device(gout.device):
             module._trunk.backward(p, tape, gout, grads)
         return (None, None, None, None, None, None, None) + tuple(grads[n] for n in names)
 
@@ -111,6 +111,20 @@ class FeedForward(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def _tensor_dict(self):
+        """state_dict-keyed parameters and buffers of THIS module instance.  A replica made by
+        nn.DataParallel (reference train/cli.py:159; torch.nn.parallel.replicate) has no registered parameters:
+        its per-device copies are plain attributes listed in `_former_parameters`, connected by autograd to the
+        master's parameters on device 0 -- which is where their gradients are reduced to."""
+        if getattr(self, '_is_replica', False):
+            d = {}
+            for prefix, mod in self.named_modules():
+                dot = prefix + '.' if prefix else ''
+                for k, t in getattr(mod, '_former_parameters', {}).items():
+                    d[dot + k] = t
+                for k, t in mod._buffers.items():
+                    if t is not None:
+                        d[dot + k] = t
+            return d
         d = {n: t for n, t in self.named_parameters()}
         d.update({n: t for n, t in self.named_buffers()})
         return d
@@ -145,9 +159,20 @@ class FeedForward(nn.Module):
             for t in stacks:
                 if t is None or not t.is_contiguous() or t.dtype != torch.float32 or t.shape != h_views.shape:
                     raise ValueError('FeedForward: four contiguous float32 (b, n, 3, h, w) stacks required')
-            params = [p for _, p in self.named_parameters()]
+                if t.device != h_views.device:
+                    raise ValueError(f'FeedForward: stacks on different devices ({t.device} vs {h_views.device})')
+            td = self._tensor_dict()
+            missing = [n for n in self._param_names if n not in td]
+            if missing:
+                raise RuntimeError(f'FeedForward: no tensor for parameter {missing[0]!r} on this module instance '
+                                   '(an unsupported kind of module copy?); use mmlf_amd.train.TrainStep for data '
+                                   'parallelism (one process per GPU)')
+            params = [td[n] for n in self._param_names]
+            if params[0].device != h_views.device:
+                raise ValueError(f'FeedForward: parameters on {params[0].device}, input on {h_views.device}')
             save = torch.is_grad_enabled() and any(t.requires_grad for t in params)
-            output = _TrunkFn.apply(self, self.training, save, *stacks, *params)
+            with torch.cuda.device(h_views.device):      # DataParallel worker threads: launch on the replica's device
+                output = _TrunkFn.apply(self, self.training, save, *stacks, *params)
         else:
             output = self._torch_trunk(h_views, v_views, i_views, d_views)
 

@@ -1,8 +1,9 @@
 """Losses and masks of the train / validate step, reference mmlf/model/loss.py.
 
 Each module takes ``(output_dict, target, mask[, mask_padding])`` like the reference.  On CUDA
-tensors the three training losses run the fused HIP kernel (value + gradient in one call,
-``mmlf_loss_fwd_bwd``) behind a small autograd node; on CPU they are plain torch expressions.
+tensors the training losses -- single-mode, multimodal and padded -- run fused HIP kernels (value +
+gradient in one call, ``mmlf_loss_fwd_bwd`` / ``mmlf_loss_multi_fwd_bwd``) behind a small autograd node;
+on CPU they are plain torch expressions.
 """
 import torch
 import torch.nn as nn
@@ -13,6 +14,7 @@ from ._lib import call, ptr
 from .engine import LOSS_BLOCKS
 
 KIND_L1, KIND_UPR, KIND_CE = 0, 1, 2
+KIND_MULTI_L1, KIND_MULTI_UPR, KIND_MULTI_CE, KIND_UPR_PADDED = 3, 4, 5, 6   # mmlf_loss_multi_fwd_bwd
 
 
 def create_mask_margin(shape, margin=0):
@@ -31,6 +33,9 @@ def native_loss(kind, output, gt, mask, grid_torch=None, half_step=0.0, want_gra
     """Fused loss on the raw trunk output (B,oc,H,W).  Returns (loss scalar tensor, grad or None)."""
     B, oc, H, W = output.shape
     dev = output.device
+    for name, t in (('target', gt), ('mask', mask), ('grid', grid_torch), ('den_override', den_override)):
+        if t is not None and t.device != dev:       # a raw pointer of another device would fault inside the kernel
+            raise ValueError(f'loss: {name} is on {t.device}, the model output on {dev}')
     output = output.contiguous()
     gt = gt.contiguous().float()
     mask = mask.contiguous().to(torch.int32)
@@ -42,6 +47,58 @@ def native_loss(kind, output, gt, mask, grid_torch=None, half_step=0.0, want_gra
     call('mmlf_loss_fwd_bwd', kind, ptr(output), oc, ptr(gt), ptr(mask), ptr(grid_torch), float(half_step),
          ptr(loss), ptr(grad), ptr(scratch), LOSS_BLOCKS, ptr(den_override), B, H, W, _lib.stream_ptr())
     return loss, grad
+
+
+def native_multi_loss(kind, output, target, mask, mask_padding=None, grid_torch=None, half_step=0.0, want_grad=True,
+                      den_override=None, aux_override=None):
+    """Fused multimodal / padded loss on the raw trunk output (B,oc,H,W); target = mpi (B,P,5,H,W), or gt (B,H,W)
+    for KIND_UPR_PADDED.  Returns (loss scalar tensor, grad or None)."""
+    B, oc, H, W = output.shape
+    dev = output.device
+    for name, t in (('target', target), ('mask', mask), ('mask_padding', mask_padding), ('grid', grid_torch),
+                    ('den_override', den_override), ('aux_override', aux_override)):
+        if t is not None and t.device != dev:
+            raise ValueError(f'loss: {name} is on {t.device}, the model output on {dev}')
+    output = output.contiguous()
+    target = target.contiguous().float()
+    P = 0
+    if kind != KIND_UPR_PADDED:
+        if target.dim() != 5 or target.shape[0] != B or target.shape[2] != 5 or tuple(target.shape[3:]) != (H, W):
+            raise ValueError(f'multimodal loss: target must be (B, P, 5, H, W), got {tuple(target.shape)}')
+        P = target.shape[1]
+    elif tuple(target.shape) != (B, H, W) or mask_padding is None:
+        raise ValueError('padded loss: target (B, H, W) and mask_padding required')
+    mask = mask.contiguous().to(torch.int32)
+    if mask_padding is not None:
+        mask_padding = mask_padding.contiguous().to(torch.int32)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    grad = None
+    if want_grad:
+        full = kind == KIND_MULTI_CE or oc == (1 if kind == KIND_MULTI_L1 else 2)
+        grad = torch.empty_like(output) if full else torch.zeros_like(output)
+    n = int(_lib.load().mmlf_loss_multi_scratch_doubles(LOSS_BLOCKS))
+    scratch = torch.empty(n, dtype=torch.float64, device=dev)
+    call('mmlf_loss_multi_fwd_bwd', kind, ptr(output), oc, ptr(target), P, ptr(mask), ptr(mask_padding),
+         ptr(grid_torch), float(half_step), ptr(loss), ptr(grad), ptr(scratch), LOSS_BLOCKS, ptr(den_override),
+         ptr(aux_override), B, H, W, _lib.stream_ptr())
+    return loss, grad
+
+
+class _NativeMultiLossFn(torch.autograd.Function):
+    """autograd node of the multimodal / padded losses for callers that go through the loss modules"""
+
+    @staticmethod
+    def forward(ctx, kind, target, mask, mask_padding, *heads):
+        out = torch.stack(list(heads), 1)
+        loss, grad = native_multi_loss(kind, out.detach(), target, mask, mask_padding)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        (grad,) = ctx.saved_tensors
+        g = grad * gl
+        return (None, None, None, None) + tuple(g[:, k] for k in range(g.shape[1]))
 
 
 class _NativeLossFn(torch.autograd.Function):
@@ -115,6 +172,8 @@ class ImprovedUncertaintyL1Loss(nn.Module):
         mean, logvar = input['mean'], input['logvar']
         if mean.is_cuda and mask_padding is None:
             return _NativeLossFn.apply(KIND_UPR, target, mask, None, 0.0, mean, logvar)
+        if mean.is_cuda:
+            return _NativeMultiLossFn.apply(KIND_UPR_PADDED, target, mask, mask_padding, mean, logvar)
         loss = torch.exp(-logvar) * torch.abs(mean - target) + logvar
         if mask_padding is not None:
             mp = mask_padding.float()
@@ -145,6 +204,8 @@ class MultiMaskedL1Loss(nn.Module):
     """loss.py:80-103: alpha-weighted L1 to every plane, masked mean."""
 
     def forward(self, input, target, mask):
+        if input['mean'].is_cuda:
+            return _NativeMultiLossFn.apply(KIND_MULTI_L1, target, mask, None, input['mean'])
         weights, targets = target[:, :, 3], target[:, :, 4]
         diff = (torch.abs(input['mean'].unsqueeze(1) - targets) * weights).sum(1)
         return _masked_mean(diff, mask)
@@ -155,8 +216,10 @@ class ImprovedMultiUncertaintyL1Loss(nn.Module):
     -logvar term on pixels without any surface (total alpha < 0.01), each side rescaled; masked mean."""
 
     def forward(self, input, target, mask, mask_padding=None):
-        weights, targets = target[:, :, 3], target[:, :, 4]
         mean, logvar = input['mean'], input['logvar']
+        if mean.is_cuda:
+            return _NativeMultiLossFn.apply(KIND_MULTI_UPR, target, mask, None, mean, logvar)
+        weights, targets = target[:, :, 3], target[:, :, 4]
         loss = torch.exp(-logvar).unsqueeze(1) * torch.abs(mean.unsqueeze(1) - targets) + logvar.unsqueeze(1)
         total = weights.sum(1)
         loss = (loss * weights).sum(1) / torch.mean(total)

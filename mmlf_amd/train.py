@@ -72,8 +72,11 @@ class GradBuckets:
 
 class TrainStep:
     def __init__(self, model, lr, variant=None, warm_start=False, cooling=0, betas=(0.9, 0.999), eps=1e-8,
-                 loss_margin=11, process_group=None, loss_multimodal=False, loss_padding=None):
+                 loss_margin=11, process_group=None, loss_multimodal=False, loss_padding=None,
+                 train_eval_mode=False, train_eval_mode_start=0):
         self.model = model
+        # --train_eval_mode / --train_eval_mode_start (train/cli.py:227-230): BatchNorm uses its running statistics
+        self.eval_mode, self.eval_mode_start = bool(train_eval_mode), int(train_eval_mode_start)
         self.lr, self.warm_start, self.cooling = float(lr), bool(warm_start), int(cooling)
         self.betas, self.eps, self.margin = betas, float(eps), int(loss_margin)
         self.variant = variant or ('upr' if model.uncert else ('dpp' if model.discrete else 'base'))
@@ -127,7 +130,10 @@ class TrainStep:
     def __call__(self, h, v, i_, d, gt, mask, iteration):
         """One optimisation step on this rank's shard.  Returns the (rank-local) loss tensor."""
         model = self.model
-        model.train()
+        if self.eval_mode and iteration >= self.eval_mode_start:
+            model.eval()
+        else:
+            model.train()
         lr = self.current_lr(iteration)
         mask = self._mask(mask)
         den = self._den_override(mask)
@@ -146,7 +152,7 @@ class TrainStep:
         model = self.model
         p = model._tensor_dict()
         with torch.no_grad():
-            out, tape = model._trunk.forward(p, [h, v, i_, d], True, True)
+            out, tape = model._trunk.forward(p, [h, v, i_, d], model.training, True)
             if self.multimodal:
                 loss, gout = self._multimodal_loss(out, gt, mask, den)
             else:
@@ -155,16 +161,30 @@ class TrainStep:
                 if kind == loss_mod.KIND_CE:
                     grid = model._grid('torch', out.device)
                     half = (model.disp_max - model.disp_min) / model.steps / 2.0
-                loss, gout = loss_mod.native_loss(kind, out, gt, mask, grid, half, True, den)
+                pad = self.loss_padding
+                if pad is not None and kind == loss_mod.KIND_UPR:     # train/cli.py:221-222: only the UPR loss takes it
+                    mp = (torch.abs(gt) < pad).int()
+                    aux = self._scaled_aux(self._aux_override(loss_mod.KIND_UPR_PADDED, gt, mp))
+                    loss, gout = loss_mod.native_multi_loss(loss_mod.KIND_UPR_PADDED, out, gt, mask, mp, None, 0.0,
+                                                            True, den, aux)
+                else:
+                    loss, gout = loss_mod.native_loss(kind, out, gt, mask, grid, half, True, den)
             on_done = (lambda key: self.buckets.ready(self.grad, key)) if self.distributed else None
             model._trunk.backward(p, tape, gout, self._grads, on_done)
         return loss
 
+    def _padded_mpi(self, mpi):
+        """--train_loss_padding with --train_loss_multimodal: planes outside the range lose their alpha
+        (train/cli.py:219-220).  The DPP target is built from the UNPADDED planes (:201-204 run before :219)."""
+        if self.loss_padding is None or self.variant == 'dpp':
+            return mpi
+        mpi = mpi.clone()
+        mpi[:, :, 3] *= (torch.abs(mpi[:, :, 4]) < self.loss_padding).float()
+        return mpi
+
     def _multimodal_heads_loss(self, heads, mpi, mask):
         model = self.model
-        if self.loss_padding is not None:                       # train/cli.py:219-220
-            mpi = mpi.clone()
-            mpi[:, :, 3] *= (torch.abs(mpi[:, :, 4]) < self.loss_padding).float()
+        mpi = self._padded_mpi(mpi)
         if self.variant == 'upr':
             return loss_mod.ImprovedMultiUncertaintyL1Loss()(heads, mpi, mask)
         if self.variant == 'dpp':
@@ -172,18 +192,34 @@ class TrainStep:
             return loss_mod.MaskedCrossEntropy()(heads, tgt, mask)
         return loss_mod.MultiMaskedL1Loss()(heads, mpi, mask)
 
+    def _aux_override(self, kind, target, mask_padding):
+        """whole-batch sums the multimodal UPR / padded UPR losses normalise by, summed over the ranks (the
+        reference evaluates the loss on the gathered batch, train/cli.py:245-255)"""
+        if not self.distributed:
+            return None
+        if kind == loss_mod.KIND_MULTI_UPR:
+            tot = target[:, :, 3].sum(1)
+            aux = torch.stack([tot.sum().double(), (tot < 0.01).sum().double()])
+        else:
+            aux = torch.stack([mask_padding.sum().double(), torch.zeros((), dtype=torch.float64, device=target.device)])
+        dist.all_reduce(aux, group=self.group)
+        return aux
+
     def _multimodal_loss(self, out, mpi, mask, den):
-        """Multimodal losses are small elementwise expressions over (B,P,H,W): evaluated with torch
-        ops and differentiated w.r.t. the raw trunk output, which feeds the native backward."""
-        with torch.enable_grad():
-            o = out.detach().requires_grad_(True)
-            heads = {'mean': o[:, 0], 'logvar': o[:, 1] if self.variant == 'upr' else None, 'scores': o}
-            loss = self._multimodal_heads_loss(heads, mpi, mask)
-            if den is not None:
-                cnt = mask.sum().double()
-                loss = loss * (cnt / den.squeeze()).float() if cnt > 0 else loss
-            (gout,) = torch.autograd.grad(loss, o)
-        return loss.detach(), gout.contiguous()
+        """multimodal losses over (B,P,5,H,W) targets: fused HIP value + gradient (mmlf_loss_multi_fwd_bwd)"""
+        model = self.model
+        mpi = self._padded_mpi(mpi)
+        kind = {'base': loss_mod.KIND_MULTI_L1, 'upr': loss_mod.KIND_MULTI_UPR, 'dpp': loss_mod.KIND_MULTI_CE}[self.variant]
+        grid, half = None, 0.0
+        if kind == loss_mod.KIND_MULTI_CE:
+            grid = model._grid('torch', out.device)
+            half = (model.disp_max - model.disp_min) / model.steps / 2.0
+        aux = self._aux_override(kind, mpi, None) if kind == loss_mod.KIND_MULTI_UPR else None
+        return loss_mod.native_multi_loss(kind, out, mpi, mask, None, grid, half, True, den, self._scaled_aux(aux))
+
+    def _scaled_aux(self, aux):
+        # the kernel forms mean = aux[0] / n_local and n_local / aux[1]: pass the global sums divided by the world size
+        return None if aux is None else aux / self.world
 
     def _torch_fwd_bwd(self, h, v, i_, d, gt, mask, den):
         model = self.model
@@ -193,7 +229,8 @@ class TrainStep:
         if self.multimodal:
             loss = self._multimodal_heads_loss(out, gt, mask)
         elif self.variant == 'upr':
-            loss = loss_mod.ImprovedUncertaintyL1Loss()(out, gt, mask, None)
+            mp = None if self.loss_padding is None else (torch.abs(gt) < self.loss_padding).int()
+            loss = loss_mod.ImprovedUncertaintyL1Loss()(out, gt, mask, mp)
         elif self.variant == 'dpp':
             tgt = dl.reg_to_class(gt, model.disp_min, model.disp_max, model.steps)
             loss = loss_mod.MaskedCrossEntropy()(out, tgt, mask)

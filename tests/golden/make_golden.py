@@ -19,6 +19,9 @@ Groups:
   G5  losses and dl helpers.
   G6  multimodal losses.
   G7  the training patch pipeline (hci4d transforms as train/cli.py composes them).
+  G8  round-2 additions: padded / multimodal loss gradients, DPP full-size train step, eval-mode training
+      (--train_eval_mode), and a checkpoint.pt written by the reference's own ModelSaver + torch.optim.Adam
+      with the state one resumed step later (g9_checkpoint.pt is a data file: tensors and hyper-parameters).
 """
 import os
 import sys
@@ -340,7 +343,131 @@ def g7_patch_pipeline():
     print('G7 ok', len(rec), 'arrays')
 
 
+def g8_extras():
+    rec = {}
+    # (a) UPR loss with mask_padding: gradients (inputs are G5's)
+    g5 = dict(np.load(os.path.join(HERE, 'g5_losses.npz')))
+    tgt, tmask, tmp = (torch.from_numpy(g5[k]) for k in ('gt', 'mask', 'mask_padding'))
+    o = {'mean': torch.from_numpy(g5['mean']).requires_grad_(True), 'logvar': torch.from_numpy(g5['logvar']).requires_grad_(True)}
+    val = ref_loss.ImprovedUncertaintyL1Loss()(o, tgt, tmask, tmp)
+    val.backward()
+    rec['upr_padding'] = val.detach().numpy()
+    rec['dupr_padding_dmean'], rec['dupr_padding_dlogvar'] = o['mean'].grad.numpy(), o['logvar'].grad.numpy()
+    # (b) multimodal: cross entropy on mpi_to_weights(mpi) and the padded multimodal L1 / UPR losses (inputs are G6's)
+    g6 = dict(np.load(os.path.join(HERE, 'g6_multimodal.npz')))
+    rs = np.random.RandomState(8)
+    B, P, _, H, W = g6['mpi'].shape
+    scores = rs.normal(scale=1.5, size=(B, 108, H, W)).astype(np.float32)
+    rec['scores'] = scores
+    tmpi, tmask6 = torch.from_numpy(g6['mpi']), torch.from_numpy(g6['mask'])
+    sc = torch.from_numpy(scores).requires_grad_(True)
+    val = ref_loss.MaskedCrossEntropy()({'scores': sc}, ref_dl.mpi_to_weights(tmpi, -3.5, 3.5, 108), tmask6)
+    val.backward()
+    rec['multi_ce'], rec['dmulti_ce_dscores'] = val.detach().numpy(), sc.grad.numpy()
+    pad = 3.0
+    mpi_p = tmpi.clone()                                   # train/cli.py:219-220
+    mpi_p[:, :, 3, :, :] *= (torch.abs(mpi_p[:, :, 4, :, :]) < pad).float()
+    rec['pad'] = np.float32(pad)
+    for name, fn, keys in (('multi_l1_pad', ref_loss.MultiMaskedL1Loss(), ['mean']),
+                           ('multi_upr_pad', ref_loss.ImprovedMultiUncertaintyL1Loss(), ['mean', 'logvar'])):
+        o = {'mean': torch.from_numpy(g6['mean']).requires_grad_(True), 'logvar': torch.from_numpy(g6['logvar']).requires_grad_(True)}
+        val = fn(o, mpi_p, tmask6)
+        val.backward()
+        rec[name] = val.detach().numpy()
+        for k in keys:
+            rec[f'd{name}_d{k}'] = o[k].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'g8_losses.npz'), **rec)
+    print('G8 losses', {k: np.asarray(v).shape for k, v in rec.items()})
+
+    # (c) DPP full-size train step (B=2): loss, sampled gradients, BN buffers
+    kw = dict(BASE_KW, model_discrete=True)
+    model, state = build_ref(kw, seed=21)
+    stacks, gt, mask = synth.synth_inputs(2, 96, seed=8)
+    m = train_mask(mask)
+    model.train()
+    model.zero_grad()
+    out = model(*[torch.from_numpy(s) for s in stacks])
+    loss = loss_for('dpp', out, torch.from_numpy(gt), m, kw)
+    loss.backward()
+    rec = {'loss': loss.detach().numpy(), 'train_scores_s': out['scores'].detach().numpy()[:, :, ::8, ::8].copy(),
+           'train_argmax': out['scores'].detach().numpy().argmax(1).astype(np.int16)}
+    for n, p in model.named_parameters():
+        g = p.grad.numpy()
+        rec[f'grad_s/{n}'] = sample(g) if g.size > 4096 else g.copy()
+    for n, v in model.state_dict().items():
+        if 'running' in n or 'num_batches' in n:
+            rec[f'post/{n}'] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'g2_full_dpp_train.npz'), **rec)
+    print('G8 dpp train loss', float(loss))
+
+    # (d) --train_eval_mode (train/cli.py:227-230): model.eval() during the optimisation step -- BatchNorm uses
+    # and does not update its running statistics, gradients flow through them as constants
+    kw = dict(TINY_KW, model_uncert=True)
+    model, state = build_ref(kw, seed=12)
+    stacks, gt, mask = synth.synth_inputs(3, 16, seed=6)
+    m = torch.from_numpy(mask).int() * ref_loss.create_mask_margin(mask.shape, 3)
+    model.eval()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt.zero_grad()
+    out = model(*[torch.from_numpy(s) for s in stacks])
+    loss = loss_for('upr', out, torch.from_numpy(gt), m, kw)
+    loss.backward()
+    rec = {'loss': loss.detach().numpy(), 'mask': m.numpy(), 'gt': gt}
+    rec.update(out_arrays({k: out[k] for k in ('mean', 'logvar')}, 'out_'))
+    for n, p in model.named_parameters():
+        rec[f'grad/{n}'] = p.grad.numpy().copy()
+    opt.step()
+    for n, v in model.state_dict().items():
+        rec[f'post/{n}'] = v.numpy().copy()
+    for i, s in enumerate(stacks):
+        rec[f'in{i}'] = s
+    np.savez_compressed(os.path.join(HERE, 'g8_evalmode_upr.npz'), **rec)
+    print('G8 eval-mode loss', float(loss))
+
+    # (e) a checkpoint written by the REFERENCE's ModelSaver after two Adam steps, and the model one resumed
+    # step later (reference resume: train/cli.py:137-157)
+    kw = dict(TINY_KW, train_lr=1e-3, model_radius=5, val_disp_step=0.1)
+    model, state = build_ref(TINY_KW, seed=4)
+    stacks, gt, mask = synth.synth_inputs(2, 16, seed=2)
+    m = torch.from_numpy(mask).int() * ref_loss.create_mask_margin(mask.shape, 3)
+    tst = [torch.from_numpy(s) for s in stacks]
+
+    def one_step(model, opt):
+        model.train()
+        opt.zero_grad()
+        l = ref_loss.MaskedL1Loss()(model(*tst), torch.from_numpy(gt), m)
+        l.backward()
+        opt.step()
+        return float(l)
+
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    for _ in range(2):
+        one_step(model, opt)
+    ref_dl.ModelSaver(only_best=False)(os.path.join(HERE, 'g9_checkpoint.pt'), torch.nn.DataParallel(model), opt, kw,
+                                       None, 2, 0.5)
+    # resume in a fresh model + optimizer, exactly as the reference does, and take one more step
+    model2 = RefFeedForward(**TINY_KW)
+    opt2 = torch.optim.Adam(model2.parameters(), lr=1e-5)
+    ck = torch.load(os.path.join(HERE, 'g9_checkpoint.pt'))
+    model2.load_state_dict(ck['model_state_dict'])
+    opt2.load_state_dict(ck['optimizer_state_dict'])
+    for gparam in opt2.param_groups:
+        gparam['lr'] = 1e-3
+    l3 = one_step(model2, opt2)
+    rec = {'loss3': np.float32(l3), 'iteration': np.int64(ck['iteration'])}
+    for n, v in model2.state_dict().items():
+        rec[f'post/{n}'] = v.numpy().copy()
+    for i, s in enumerate(stacks):
+        rec[f'in{i}'] = s
+    rec['gt'], rec['mask'] = gt, m.numpy()
+    np.savez_compressed(os.path.join(HERE, 'g9_checkpoint_next.npz'), **rec)
+    print('G9 checkpoint', os.path.getsize(os.path.join(HERE, 'g9_checkpoint.pt')), 'bytes; resumed loss', l3)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'g8':
+        g8_extras()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g6':
         g6_multimodal()
         sys.exit(0)
@@ -353,6 +480,7 @@ if __name__ == '__main__':
     g2_full()
     g6_multimodal()
     g7_patch_pipeline()
+    g8_extras()
     sizes = {f: os.path.getsize(os.path.join(HERE, f)) for f in sorted(os.listdir(HERE))
              if f.endswith('.npz')}
     print(sizes)

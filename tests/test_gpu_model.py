@@ -114,10 +114,10 @@ def test_g2_full_size_eval_depth_mae(variant):
         assert np.abs(out['logvar'].cpu().numpy() - g['eval_logvar'])[ok].mean() <= 1e-3
 
 
-@pytest.mark.parametrize('variant', ['base', 'upr'])
+@pytest.mark.parametrize('variant', ['base', 'upr', 'dpp'])
 def test_g2_full_size_train_step_vs_reference(variant):
     from mmlf_amd.loss import create_mask_margin
-    g = load_golden(f'g2_full_{variant}.npz')
+    g = load_golden('g2_full_dpp_train.npz' if variant == 'dpp' else f'g2_full_{variant}.npz')
     kw = dict(BASE_KW, **VARIANTS[variant])
     dev = _dev()
     m = _model(kw, synth.synth_state(synth.param_spec(**kw), seed=21))
@@ -125,7 +125,12 @@ def test_g2_full_size_train_step_vs_reference(variant):
     mask = torch.from_numpy(mask).int() * create_mask_margin(mask.shape, 11)
     m.train()
     out = m(*[torch.from_numpy(s).to(dev) for s in stacks])
-    assert np.abs(out['mean'].detach().cpu().numpy() - g['train_mean']).mean() <= DEPTH_MAE_TOL
+    if variant == 'dpp':     # the 280->108 and 108->108 head convolutions inside the real net, forward and backward
+        sc = out['scores'].detach().cpu().numpy()
+        np.testing.assert_allclose(sc[:, :, ::8, ::8], g['train_scores_s'], rtol=2e-4, atol=5e-5)
+        assert (sc.argmax(1) != g['train_argmax']).mean() <= 0.0015
+    else:
+        assert np.abs(out['mean'].detach().cpu().numpy() - g['train_mean']).mean() <= DEPTH_MAE_TOL
     loss = _loss_fn(variant)(out, torch.from_numpy(gt).to(dev), mask.to(dev))
     np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-4)
     loss.backward()
