@@ -31,55 +31,133 @@ BASE_KW = dict(model_ksize=2, model_in_blocks=3, model_out_blocks=8, model_chs=7
 GFLOP_PER_PATCH = {'base': 268.373, 'upr': 268.437, 'dpp': 277.718}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 / f16 MFMA; the split kernels spend 3 (f16x3) or 6 (bf16x6) passes per f32 product
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01i_pmc_bs512_base_summary.json')
+PMC_SUMMARIES = [os.path.join(ROOT, 'profiles', n) for n in ('r02_pmc_bs512_base_summary.json',
+                                                                'r01i_pmc_bs512_base_summary.json')]
+KW_EXTRA = {'base': {}, 'upr': {'model_uncert': True}, 'dpp': {'model_discrete': True}}
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     WRITE_SIZE runs of this same command; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes)."""
-    try:
-        with open(PMC_SUMMARY) as f:
-            d = json.load(f)
-        for k, v in d.items():
-            if kernel in k:
-                return round(v['hbm_bytes_per_launch'])
-    except (OSError, ValueError, KeyError):
-        pass
+    for path in PMC_SUMMARIES:
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            for k, v in d.items():
+                if kernel in k:
+                    return round(v['hbm_bytes_per_launch'])
+        except (OSError, ValueError, KeyError):
+            pass
     return None
 
 
+def host_threads():
+    """threads this process may actually use (the GPU box gives a 1-GPU job a share of the host's cores)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:                                     # cgroup v2 CPU quota, if any
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(variant, patch):
-    """The oracle (float-accumulating build of oracle/mmlf_oracle.c + numpy) timed on the host cores:
-    one fwd + loss + bwd + Adam step on a bounded sample (B=8 patches)."""
-    import numpy as np
-    from mmlf_amd import synth
-    from oracle import oracle as orc
-    kw = dict(BASE_KW, **{'upr': {'model_uncert': True}, 'dpp': {'model_discrete': True}}.get(variant, {}))
-    cores = os.cpu_count() or 1
-    os.environ['OMP_NUM_THREADS'] = str(cores)
-    orc.build()
-    state = synth.synth_state(synth.param_spec(**kw), seed=0, trained_like=False)
+    """The reference's CPU arithmetic on the host cores of this box: mmlf_amd.FeedForward on CPU tensors runs the
+    module tree with the stock torch (mkldnn) ops the reference executes -- nn.Conv2d / BatchNorm2d / ReLU,
+    autograd backward -- and TrainStep's CPU branch does zero_grad / loss / backward / Adam like
+    mmlf/train/cli.py:243-258.  (The reference itself cannot travel to the GPU box.)  BASELINE.md section 4:
+    B=8, 1 warm-up + 3 timed iterations, median."""
+    import statistics
+    from mmlf_amd.feed_forward import FeedForward
+    from mmlf_amd.train import TrainStep
+    kw = dict(BASE_KW, **KW_EXTRA[variant])
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = FeedForward(**kw)
+    step = TrainStep(model, lr=1e-3, loss_margin=11)
     B = 8
-    stacks, gt, mask = synth.synth_inputs(B, patch, seed=0)
-    mask = mask * orc.create_mask_margin(mask.shape, 11)
-    net = orc.OracleNet(kw, state, acc='f32')
-    names = [k for k in state if state[k].dtype == np.float32 and 'running' not in k]
+    g = torch.Generator().manual_seed(0)
+    stacks = [torch.rand((B, 9, 3, patch, patch), generator=g) for _ in range(4)]
+    gt = 4.0 * torch.rand((B, patch, patch), generator=g) - 2.0
+    mask = torch.ones((B, patch, patch), dtype=torch.int32)
+    times = []
+    for it in range(4):
+        t0 = time.time()
+        step(*stacks, gt, mask, it + 1)
+        times.append(time.time() - t0)
+    med = statistics.median(times[1:])
+    return {'value': round(B / med, 4), 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{variant.upper()} fwd+loss+bwd+Adam on B={B} patches {patch}x{patch}, stock torch CPU ops '
+                      f'(mkldnn conv / native_batch_norm / autograd, the ops the reference runs), {cores} threads, '
+                      f'1 warm-up + 3 timed steps, median {med:.2f} s/step'}
 
-    def one_step():
-        out = net.forward(*stacks, train=True)
-        _, dldo = orc.masked_l1(out, gt, mask)
-        grads = net.backward(net.head_grad(dldo))
-        params = {n: net.state[n] for n in names}
-        m = {n: np.zeros_like(params[n]) for n in names}
-        v = {n: np.zeros_like(params[n]) for n in names}
-        orc.adam_step(params, grads, m, v, step=1, lr=1e-3)
 
+def make_step(variant, B, patch, dev, seed):
+    from mmlf_amd.feed_forward import FeedForward
+    from mmlf_amd.train import TrainStep
+    kw = dict(BASE_KW, **KW_EXTRA[variant])
+    torch.manual_seed(0)
+    model = FeedForward(**kw).to(dev)
+    step = TrainStep(model, lr=1e-3, loss_margin=11)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    stacks = [torch.rand((B, 9, 3, patch, patch), device=dev, generator=gen) for _ in range(4)]
+    gt = 4.0 * torch.rand((B, patch, patch), device=dev, generator=gen) - 2.0
+    mask = torch.ones((B, patch, patch), dtype=torch.int32, device=dev)
+    return step, stacks, gt, mask
+
+
+def extra_leg(variant, B, patch, dev, steps, peak):
+    """one more BASELINE.json config through the same train step, single GPU: value + whole-step TFLOP/s"""
+    step, stacks, gt, mask = make_step(variant, B, patch, dev, seed=1)
+    step(*stacks, gt, mask, 1)
+    torch.cuda.synchronize()
     t0 = time.time()
-    one_step()
+    for it in range(steps):
+        loss = step(*stacks, gt, mask, 2 + it)
+    torch.cuda.synchronize()
     dt = time.time() - t0
-    return {'value': round(B / dt, 4), 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 step, B={B} patches {patch}x{patch}, BASE fwd+loss+bwd+Adam, oracle C/numpy float accumulate, '
-                      f'{cores} OpenMP threads, {dt:.1f} s'}
+    value = B * steps / dt
+    tf = value * GFLOP_PER_PATCH[variant] * (patch / 96.0) ** 2 / 1e3
+    out = {'value': round(value, 2), 'unit': 'patches/s', 'steps': steps, 'per_gpu_batch': B,
+           'ms_per_step': round(1e3 * dt / steps, 2), 'whole_step_tflops': round(tf, 1),
+           'frac_of_peak': round(tf / peak, 4), 'loss': round(float(loss), 6)}
+    del step, stacks, gt, mask
+    torch.cuda.empty_cache()
+    return out
+
+
+def ese_leg(dev, peak, size=512):
+    """BASELINE.json configs[4] on one GPU: one 512x512 light field through the 70-member Ensamble (eval)"""
+    from mmlf_amd.ensamble import Ensamble
+    from mmlf_amd.feed_forward import FeedForward
+    torch.manual_seed(0)
+    model = FeedForward(**dict(BASE_KW, model_uncert=True)).to(dev).eval()
+    ens = Ensamble(model, -3.5, 3.5, 0.1).eval()
+    gen = torch.Generator(device=dev).manual_seed(2)
+    stacks = [torch.rand((1, 9, 3, size, size), device=dev, generator=gen) for _ in range(4)]
+    times = []
+    with torch.no_grad():
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            out = ens(*stacks)
+            torch.cuda.synchronize()
+            times.append(time.time() - t0)
+    dt = min(times[1:])
+    tf = 70 * 2529.3 * (size / 512.0) ** 2 / dt / 1e3          # SURVEY section 8d: 2529.3 GFLOP per 512^2 UPR forward
+    res = {'value': round(dt, 4), 'unit': 's/scene', 'higher_is_better': False, 'members': 70, 'frame': f'{size}x{size}',
+           'algorithmic_tflops': round(tf, 1), 'frac_of_peak': round(tf / peak, 4),
+           'finite': bool(torch.isfinite(out['mean']).all())}
+    del ens, model, stacks, out
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -92,6 +170,9 @@ def main():
     ap.add_argument('--patch', type=int, default=96)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the extra exact-f32-MFMA measurement')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip the UPR / DPP / shard-64 / ESE measurements')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo: rehearsal of the N>1 path with every rank on whatever GPUs exist (one is enough)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -102,25 +183,20 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.backend == 'gloo' else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':       # RCCL over xGMI
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     from mmlf_amd import engine
-    from mmlf_amd.feed_forward import FeedForward
-    from mmlf_amd.train import TrainStep
 
     assert args.global_batch % world == 0
     B = args.global_batch // world
-    kw = dict(BASE_KW, **{'upr': {'model_uncert': True}, 'dpp': {'model_discrete': True}}.get(args.variant, {}))
-    torch.manual_seed(0)
-    model = FeedForward(**kw).to(dev)
-    step = TrainStep(model, lr=1e-3, loss_margin=11)
-    gen = torch.Generator(device=dev).manual_seed(rank)
-    stacks = [torch.rand((B, 9, 3, args.patch, args.patch), device=dev, generator=gen) for _ in range(4)]
-    gt = 4.0 * torch.rand((B, args.patch, args.patch), device=dev, generator=gen) - 2.0
-    mask = torch.ones((B, args.patch, args.patch), dtype=torch.int32, device=dev)
+    step, stacks, gt, mask = make_step(args.variant, B, args.patch, dev, seed=rank)
 
     def sync():
         if world > 1:
@@ -175,8 +251,9 @@ def main():
         split = passes is not None
         peak = PEAK_BF16_MFMA_TFLOPS / passes if split else PEAK_F32_MFMA_TFLOPS
         kname = f'conv4tap_x6s_kernel<18, {2 if passes == 3 else 3}>' if split else 'conv4tap_kernel<9>'
-        dtype = {'f16x3': 'f32 (exact 2-way f16 split of power-of-two-scaled operands, 3 MFMA passes, f32 accumulate)',
-                 'bf16x6': 'f32 (exact 3-way bf16 split, 6 MFMA passes, f32 accumulate)'}.get(engine.CONV_MODE, 'f32')
+        dtype = {'f16x3': 'f32 via 2 x f16 operand split (22 significant bits per operand, locally scaled; 3 MFMA '
+                          'passes, f32 accumulate)',
+                 'bf16x6': 'f32 via exact 3 x bf16 operand split (6 MFMA passes, f32 accumulate)'}.get(engine.CONV_MODE, 'f32')
         line = {
             'metric': '96x96 EPI patches/sec fwd+bwd, bs=512', 'value': round(value, 3), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
@@ -196,8 +273,19 @@ def main():
                          'algorithmic_bytes': round(2.0 * B * 98 * 98 * 280 * 4) if args.patch == 96 else None,
                          'launches': len(prof), 'avg_ms': round(1e3 * secs / max(1, len(prof)), 3)},
         }
+        if args.backend != 'nccl':
+            line['config']['backend'] = args.backend + ' (rehearsal: not an xGMI measurement)'
         if f32_leg is not None:
             line['exact_f32_mfma_path'] = f32_leg
+        if world == 1 and not args.no_extra_legs and args.global_batch == 512 and args.patch == 96:
+            # the other BASELINE.json configs, driver-timed in the same run (single GPU each)
+            del step, stacks, gt, mask
+            torch.cuda.empty_cache()
+            for key, (variant, b, n) in {'upr': ('upr', 512, 2), 'dpp': ('dpp', 512, 2), 'shard64': ('base', 64, 5)}.items():
+                if key != args.variant:
+                    line[key] = extra_leg(variant, b, 96, dev, n, peak)
+            line['shard64']['note'] = 'the per-GPU share of the bs=512 batch on 8 GPUs (configs[3] shape), one GPU, no collective'
+            line['ese'] = ese_leg(dev, peak)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.patch)
         print(json.dumps(line), flush=True)

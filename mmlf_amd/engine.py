@@ -6,6 +6,7 @@ step is a call through the C ABI (include/mmlf_hip.h).
 Layout and indexing are described in include/mmlf_hip.h and DESIGN.md section 3.
 """
 import os
+import threading
 
 import torch
 
@@ -52,12 +53,14 @@ class Geometry:
 
 
 class _Workspace:
-    """Per-device scratch that is reused across calls (stream-ordered, single stream)."""
+    """Scratch that is reused across calls (stream-ordered, single stream), one per (device, calling thread):
+    nn.DataParallel drives replicas from one thread per device -- and nothing stops two of them from sharing a
+    device -- while autograd's backward runs on its own thread per device."""
     _cache = {}
 
     @classmethod
     def get(cls, device):
-        key = (device.type, device.index)
+        key = (device.type, device.index, threading.get_ident())
         ws = cls._cache.get(key)
         if ws is None:
             ws = cls._cache[key] = cls(device)

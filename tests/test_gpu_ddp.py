@@ -89,3 +89,44 @@ def test_two_ranks_one_gpu_native_path(tmp_path):
             st.adam_steps += 1
             st._adam(st.current_lr(it), 1.0)
     torch.testing.assert_close(r0['flat'][solid.cpu()], steps[0].flat.cpu()[solid.cpu()], rtol=1e-4, atol=3e-5)
+    # ... and an INDEPENDENT reference: the same two shards through the stock-torch module path on the CPU
+    # (nn.Conv2d / BatchNorm2d / autograd), gradients averaged by hand, the same Adam arithmetic
+    cpu_steps = [TrainStep(_make(3).cpu(), lr=1e-2, loss_margin=3) for _ in range(2)]
+    cstacks, cgt, cmargin = [s.cpu() for s in stacks], gt.cpu(), margin.cpu()
+    for it in (1, 2):
+        for r, st in enumerate(cpu_steps):
+            st.grad.zero_()
+            st.model.train()
+            den = torch.tensor([total / 2], dtype=torch.float64)
+            loss = st._torch_fwd_bwd(*[s[2 * r:2 * r + 2].contiguous() for s in cstacks], cgt[2 * r:2 * r + 2].contiguous(),
+                                     cmargin[2 * r:2 * r + 2].contiguous(), den)
+            if r == 0:
+                np.testing.assert_allclose(float(loss), r0['losses'][it - 1], rtol=2e-5)
+        avg = (cpu_steps[0].grad + cpu_steps[1].grad) / 2
+        for st in cpu_steps:
+            st.grad.copy_(avg)
+            st.adam_steps += 1
+            st._adam(st.current_lr(it), 1.0)
+    torch.testing.assert_close(r0['flat'][solid.cpu()], cpu_steps[0].flat[solid.cpu()], rtol=1e-4, atol=3e-5)
+
+
+def test_bench_two_ranks_gloo_rehearsal(tmp_path):
+    """bench.py's N>1 path end to end on the one GPU of this box: torch.distributed.run launcher, process-group
+    init, sharded batch, bucketed all-reduce hooks fired from the native backward, max-over-ranks timing and rank 0's
+    JSON line -- with gloo standing in for RCCL (`--backend gloo`; the 8-GPU RCCL run is the driver's)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--global-batch', '8',
+           '--patch', '32', '--steps', '1', '--warmup', '1', '--backend', 'gloo', '--no-cpu-baseline', '--no-f32-leg']
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]            # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['config']['per_gpu_batch'] == 4 and line['config']['parallelism'] == 'dp2'
+    assert line['scaling'] == 'strong' and line['value'] > 0 and np.isfinite(line['config']['loss'])
+    assert 'gloo' in line['config']['backend']

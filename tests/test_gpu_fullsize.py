@@ -1,0 +1,157 @@
+"""BASELINE.json's full size (bs=512, ps=96) end to end, where the CPU oracle is too slow: size-independent
+properties of the whole path and an independent full-size reference -- the SAME module run with the stock torch
+(MIOpen / ATen) ops on the same GPU, which is what the reference itself executes on a GPU
+(mmlf/model/feed_forward.py:123-135).  Run on the MI355X box:  python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import BASE_KW
+from mmlf_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEPTH_MAE_TOL = 1e-4           # north_star: per-pixel depth MAE vs the reference
+
+
+def _model(kw, seed, trained_like=True):
+    from mmlf_amd.feed_forward import FeedForward
+    m = FeedForward(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in
+                       synth.synth_state(synth.param_spec(**kw), seed=seed).items()})
+    return m.to('cuda:0')
+
+
+def _inputs(B, seed):
+    gen = torch.Generator(device='cuda:0').manual_seed(seed)
+    stacks = [torch.rand((B, 9, 3, 96, 96), device='cuda:0', generator=gen) for _ in range(4)]
+    gt = 4.0 * torch.rand((B, 96, 96), device='cuda:0', generator=gen) - 2.0
+    return stacks, gt
+
+
+def test_eval_forward_bs512_equals_eight_shards_bit_for_bit():
+    """eval mode is batch-independent, and the f16-split scales are local (per wave, from the grid rows it reads):
+    the bs=512 forward must equal the concatenation of its eight 64-patch shards EXACTLY (64 patches are a whole
+    number of 256-position tiles, so every wave sees the same operands in both runs)."""
+    m = _model(dict(BASE_KW, model_uncert=True), seed=21)
+    m.eval()
+    stacks, _ = _inputs(512, 1)
+    with torch.no_grad():
+        full = m(*stacks)
+        for s in range(8):
+            part = m(*[t[64 * s:64 * s + 64].contiguous() for t in stacks])
+            for k in ('mean', 'logvar'):
+                assert torch.equal(part[k], full[k][64 * s:64 * s + 64]), (k, s)
+    assert torch.isfinite(full['mean']).all()
+
+
+@pytest.mark.parametrize('variant', ['base', 'dpp'])
+def test_train_forward_and_loss_bs512_vs_stock_torch_ops(variant):
+    """train-mode forward at bs=512 -- BatchNorm statistics over 4.7 M positions from the convolution epilogues,
+    per-call statistics of the shared stream nets, running-statistics update, head, loss -- against the stock torch
+    ops on the same inputs."""
+    from mmlf_amd import dl, loss
+    kw = dict(BASE_KW, model_discrete=(variant == 'dpp'))
+    stacks, gt = _inputs(512, 2)
+    mask = (torch.ones((512, 96, 96), dtype=torch.int32) * loss.create_mask_margin((512, 96, 96), 11)).to('cuda:0')
+    res = {}
+    for path in ('native', 'torch'):
+        m = _model(kw, seed=21)
+        m.train()
+        if path == 'torch':
+            m._native_ok = False                 # the module tree with torch's own conv / batch_norm / relu kernels
+        with torch.no_grad():
+            out = m(*stacks)
+            if variant == 'dpp':
+                l = loss.MaskedCrossEntropy()(out, dl.reg_to_class(gt, -3.5, 3.5, 108), mask)
+            else:
+                l = loss.MaskedL1Loss()(out, gt, mask)
+        key = 'scores' if variant == 'dpp' else 'mean'
+        res[path] = (out[key].float().cpu(), float(l), {k: v.cpu() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k})
+        del m, out
+        torch.cuda.empty_cache()
+    a, b = res['native'], res['torch']
+    if variant == 'dpp':
+        assert float((a[0] - b[0]).abs().mean()) <= 2e-4
+        flips = float((a[0].argmax(1) != b[0].argmax(1)).float().mean())
+        assert flips <= 0.0015, flips
+    else:
+        assert float((a[0] - b[0]).abs().mean()) <= DEPTH_MAE_TOL
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-4)
+    for k in b[2]:
+        if 'num_batches' in k:
+            assert int(a[2][k]) == int(b[2][k]), k
+        else:
+            torch.testing.assert_close(a[2][k], b[2][k], rtol=2e-4, atol=2e-6, msg=k)
+
+
+def test_train_step_gradients_bs128_vs_stock_torch_autograd():
+    """full-width fwd + loss + bwd at 128 patches (the largest batch torch's own autograd fits beside ours):
+    every parameter gradient against stock torch ops + autograd; end-to-end gradients are ill-conditioned
+    (DESIGN.md section 2), 3 % relative L2 per tensor is the bar the goldens use too."""
+    from mmlf_amd import loss
+    kw = dict(BASE_KW, model_uncert=True)
+    stacks, gt = _inputs(128, 3)
+    mask = (torch.ones((128, 96, 96), dtype=torch.int32) * loss.create_mask_margin((128, 96, 96), 11)).to('cuda:0')
+    grads = {}
+    for path in ('native', 'torch'):
+        m = _model(kw, seed=22)
+        m.train()
+        if path == 'torch':
+            m._native_ok = False
+        out = m(*stacks)
+        mean, logvar = out['mean'], out['logvar']
+        lossv = (torch.exp(-logvar) * torch.abs(mean - gt) + logvar)          # plain torch expression on both paths
+        lossv = (lossv * mask.float()).sum() / mask.sum()
+        lossv.backward()
+        grads[path] = (float(lossv), {n: p.grad.cpu() for n, p in m.named_parameters()})
+        del m, out, lossv
+        torch.cuda.empty_cache()
+    np.testing.assert_allclose(grads['native'][0], grads['torch'][0], rtol=1e-4)
+    floor = 1e-4 * max(float(g.norm()) for g in grads['torch'][1].values())
+    for n, ref in grads['torch'][1].items():
+        if n.endswith('.2.bias') and not n.startswith('out_net.7.'):
+            continue        # conv bias in front of BatchNorm: true-zero gradient, noise on both paths
+        got = grads['native'][1][n]
+        assert float((got - ref).norm()) <= 3e-2 * float(ref.norm()) + floor, n
+
+
+@pytest.mark.parametrize('C', [280, 70])
+def test_fused_batchnorm_statistics_bs512_vs_float64(C):
+    """the pad-0 convolution's epilogue statistics at bs=512 (4 718 592 positions per channel) against a float64
+    reduction of the stored output"""
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    dev = torch.device('cuda:0')
+    B, H, W = 512, 96, 96
+    geo = engine.Geometry(B, H, W)
+    cs = engine.cs_of(C)
+    gen = torch.Generator(device=dev).manual_seed(C)
+    x = geo.buf(cs, dev)
+    v = x[:geo.NQ * cs].view(B, geo.R, geo.P, cs)
+    v.zero_()
+    v[:, :H + 1, :W + 1, :C] = torch.rand((B, H + 1, W + 1, C), device=dev, generator=gen)
+    x.absmax = geo.amax_of(x, cs)
+    w = (torch.rand((C, C, 2, 2), device=dev, generator=gen) - 0.5) * 0.1
+    bias = torch.rand(C, device=dev, generator=gen) - 0.5
+    z = geo.buf(cs, dev)
+    ws = engine._Workspace.get(dev)
+    engine.conv(geo, x, cs, C, engine.pack_filter(w, 0, False), bias, C, z, cs, geo.P + 1, H, W, False, bn_partial=ws.partial)
+    nblk = int(_lib.load().mmlf_conv2x2_blocks(C, B, H, W))
+    c = torch.empty(4 * C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    call('mmlf_bn_stats_finalize', ptr(ws.partial), nblk, C, None, None, ptr(rm), ptr(rv), 1.0, 1e-5,
+         ptr(c[2 * C:]), ptr(c[3 * C:]), ptr(c), ptr(c[C:]), B, H, W, _lib.stream_ptr())
+    zi = z[:geo.NQ * cs].view(B, geo.R, geo.P, cs)[:, 1:H + 1, 1:W + 1, :C]
+    n = B * H * W
+    s1 = torch.zeros(C, dtype=torch.float64, device=dev)
+    s2 = torch.zeros(C, dtype=torch.float64, device=dev)
+    for b0 in range(0, B, 64):                     # float64 in slabs
+        zd = zi[b0:b0 + 64].double()
+        s1 += zd.sum((0, 1, 2))
+        s2 += (zd * zd).sum((0, 1, 2))
+    mean = s1 / n
+    var = s2 / n - mean * mean
+    torch.testing.assert_close(c[2 * C:3 * C].double(), mean, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(c[3 * C:].double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-6, atol=0)
+    torch.testing.assert_close(rv.double(), var * n / (n - 1), rtol=2e-6, atol=0)      # momentum 1: the unbiased batch variance
+    assert torch.equal(z.absmax, geo.amax_of(z, cs))
