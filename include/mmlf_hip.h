@@ -100,7 +100,12 @@ int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const
                     float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
                     int B, int H, int W, int relu, const float *relu_ref, int cs_ref,
                     const float *in_amax /* amax array of `in` */, float *out_amax /* nullable: amax array of `out` */,
-                    double *bn_partial /* nullable: see mmlf_bn_stats_finalize */, void *stream);
+                    double *bn_partial /* nullable: see mmlf_bn_stats_finalize */,
+                    uint32_t *relu_mask_out /* nullable */, const uint32_t *relu_mask_in /* nullable */, void *stream);
+/* ReLU masks as bits (mmlf_relu_mask_words(B,H,W) words): relu_mask_out receives (out > 0) of every element of
+ * this launch; relu_mask_in -- the mask a launch with the same (B,H,W) and N wrote -- replaces relu_ref in the data
+ * gradient (nn.ReLU backward, feed_forward.py:124): the layer's activations are not read again. */
+int64_t mmlf_relu_mask_words(int B, int H, int W);
 /* number of workgroups mmlf_conv2x2_h2 launches for this shape (= rows of bn_partial) */
 int mmlf_conv2x2_blocks(int N, int B, int H, int W);
 

@@ -31,7 +31,8 @@ SIGNATURES = {
     'mmlf_packed_filter_h2_bytes': (_i64, [_i, _i]),
     'mmlf_amax_entries': (_i64, [_i, _i, _i]),
     'mmlf_pack_filter_h2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    'mmlf_conv2x2_h2': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    'mmlf_conv2x2_h2': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'mmlf_relu_mask_words': (_i64, [_i, _i, _i]),
     'mmlf_conv2x2_blocks': (_i, [_i, _i, _i, _i]),
     'mmlf_bn_stats_finalize': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mmlf_conv2x2_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),

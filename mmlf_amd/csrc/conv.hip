@@ -59,6 +59,8 @@ struct ConvArgs {
     int R;
     double *bn_partial;                  // optional (f16 split): per-workgroup sums of out and out^2 per channel,
                                          // [block][2][n_true] doubles, the input of the BatchNorm finalize
+    unsigned *relu_mask_out;             // optional: (out > 0) as bits, [tile][wave][8 rows][64 lanes] words, bit = column block
+    const unsigned *relu_mask_in;        // optional: such a mask instead of relu_ref (same launch geometry and N)
 };
 
 // epilogue shared by the f32 and the split-bf16 kernels: D[row = position][col = channel]; a lane
@@ -299,16 +301,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // With a.out_amax the wave also raises the output's amax array: its 32 positions lie in at most two grid rows
 // when P >= 32 (exact row maxima); for smaller pitches the rows behind the first get the common maximum
 // (an upper bound, which is all the consumers need).
-template <int G>
+// EPI selects what the epilogue is compiled for: EPI_GENERIC reads every option from the launch arguments at run
+// time; the other values are the launch kinds of a training step, each compiled WITHOUT the code of the others (the
+// generic form carries the registers and branches of all options through every launch: 2-3 % of a 280-channel one).
+enum { EPI_GENERIC = -1, EPI_PLAIN = 0, EPI_RELU = 1, EPI_STATS = 2, EPI_BITS_IN = 4, EPI_REF_IN = 8, EPI_MASK_OUT = 16 };
+template <int G, int EPI>
 __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (&acc)[2][G], long long Q0, int w,
                                                 int r16, int q4, float unscale_a, float &run_max,
-                                                double *stats /* this wave's [16*G][2] sums, or null */)
+                                                double *stats_in /* this wave's [16*G][2] sums, or null */)
 {
+    constexpr bool GEN = EPI == EPI_GENERIC;
+    const bool do_relu = GEN ? a.relu != 0 : (EPI & EPI_RELU) != 0;
+    double *const stats = (GEN || (EPI & EPI_STATS)) ? stats_in : nullptr;
+    const bool mask_out = GEN ? a.relu_mask_out != nullptr : (EPI & EPI_MASK_OUT) != 0;
     const unsigned m = wave_row_mask(a, Q0, w, r16 + 16 * q4) >> (4 * q4);
     const long long qb = Q0 + 32 * w + a.out_shift;                                     // wave-uniform
     const __amdgpu_buffer_rsrc_t ob =
         __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)qb * a.cs_out, 0, 0x7fffffff, MMLF_BUF_FLAGS);
-    const bool has_ref = a.ref != nullptr;
+    const bool has_ref = GEN ? a.ref != nullptr : (EPI & EPI_REF_IN) != 0;
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(has_ref ? a.ref + (size_t)qb * a.cs_ref : a.out), 0, 0x7fffffff, MMLF_BUF_FLAGS);
     unsigned lo = ((unsigned)(4 * q4) * a.cs_out + r16) * 4u;
@@ -317,6 +327,15 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
     float mk[8];                             // max |out| per position this lane holds (over the column blocks)
 #pragma unroll
     for (int k = 0; k < 8; ++k) mk[k] = 0.f;
+    // ReLU masks as bits: the forward pass leaves (out > 0) of every element it wrote in the accumulator layout of
+    // THIS kernel -- word (tile, wave, row k, lane), bit = column block -- and the data gradient of the layer above
+    // (same grid, same N, hence the same layout) reads its eight words with eight coalesced loads up front instead of
+    // 8 x G scattered loads of the activations between its stores (a fifth of that launch)
+    const bool use_bits = GEN ? a.relu_mask_in != nullptr : (EPI & EPI_BITS_IN) != 0;
+    const size_t mbase = ((size_t)(Q0 / MMLF_TILE) * 8 + w) * 512 + (r16 + 16 * q4);
+    unsigned mw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mw[k] = use_bits ? a.relu_mask_in[mbase + 64 * k] : 0u;
 #pragma unroll
     for (int nb = 0; nb < G; ++nb) {
         const int ch = 16 * nb + r16;
@@ -325,7 +344,11 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
         const float uw = a.w_unscale ? a.w_unscale[ch] : 1.f;
         unsigned keep = m;
         float s1 = 0.f, s2 = 0.f;
-        if (has_ref) {
+        if (use_bits) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (!(mw[k] >> nb & 1)) keep &= ~(1u << (16 * (k >> 2) + (k & 3)));
+        } else if (has_ref) {
             float rv[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
@@ -339,8 +362,9 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
         for (int k = 0; k < 8; ++k) {
             const int rc = 16 * (k >> 2) + (k & 3);
             float v = acc[k >> 2][nb][k & 3] * unscale_a * uw + bvn;   // exact: powers of two (1 on the bf16 path)
-            if (a.relu) v = fmaxf(v, 0.f);
+            if (do_relu) v = fmaxf(v, 0.f);
             v = (keep >> rc & 1) ? v : 0.f;
+            if (mask_out) mw[k] |= (v > 0.f ? 1u : 0u) << nb;
             mk[k] = fmaxf(mk[k], fabsf(v));
             s1 += v;
             s2 = fmaf(v, v, s2);
@@ -355,6 +379,10 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
                 stats[2 * (16 * nb + r16) + 1] += (double)s2;
             }
         }
+    }
+    if (mask_out) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a.relu_mask_out[mbase + 64 * k] = mw[k];
     }
     if (a.out_amax) {
         const unsigned d0 = (unsigned)qb;                       // first destination position of the wave
@@ -434,7 +462,7 @@ __device__ __forceinline__ ConvArgs late_args()
 // columns instead of 96), 6, 7, 8 or 18.
 // PL = operand planes: 3 = bf16 3-way split, six passes ("bf16x6"); 2 = f16 2-way split of the scaled
 // operands, three passes ("f16x3").
-template <int G, int PL>
+template <int G, int PL, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
 {
     constexpr int NP = G * 16;
@@ -642,7 +670,7 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
             if constexpr (PL == 2)
                 if (tile + (int)gridDim.x < ntiles)
                     next_amax = wave_operand_amax_gather(e, (long long)(tile + gridDim.x) * MMLF_TILE, w, lane);
-            conv_epilogue16<G>(e, acc, (long long)tile * MMLF_TILE, w, r16, q4, unscale_a, run_max,
+            conv_epilogue16<G, EPI>(e, acc, (long long)tile * MMLF_TILE, w, r16, q4, unscale_a, run_max,
                                e.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -1536,6 +1564,7 @@ extern "C" int mmlf_conv2x2(const float *in, int cs_in, int K, const float *pack
     a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
     a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
     a.divP = make_magic((unsigned)g.P); a.divR = make_magic((unsigned)g.R); a.R = g.R;
+    a.relu_mask_out = nullptr; a.relu_mask_in = nullptr;
     MMLF_CHECK_ARG(g.NQpad + g.P + 64 < (1ll << 31), "mmlf_conv2x2: batch x image too large for 32-bit grid positions");
     const long long ntiles = g.NQpad / MMLF_TILE;
     hipStream_t st = (hipStream_t)stream;
@@ -1737,20 +1766,41 @@ static long long conv_split_blocks(int G, long long ntiles)
     return grid > ntiles ? ntiles : grid;
 }
 
-template <int G, int PL>
-static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
+template <int G, int PL, int EPI>
+static int launch_conv_x6s_epi(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
     constexpr size_t lds_pipe = 2 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
     constexpr size_t lds_stats = 8 * (G * 16) * 2 * sizeof(double);
     static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_pipe + (PL == 2 ? lds_stats : 0)));
     }
     const size_t lds = lds_pipe + (a.bn_partial ? lds_stats : 0);
     const long long grid = conv_split_blocks(G, ntiles);
-    hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL>), dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
+    hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI>), dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
     return mmlf_launch_status(PL == 3 ? "mmlf_conv2x2_split" : "mmlf_conv2x2_h2");
+}
+
+// the launch kinds of a training step get their own epilogue build on the hot shapes (f16 split, 70- and 280-wide
+// layers); every other combination of options runs the generic one
+template <int G, int PL>
+static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
+{
+    if constexpr (PL == 2 && (G == 5 || G == 18)) {
+        const int kind = (a.relu ? EPI_RELU : 0) | (a.bn_partial ? EPI_STATS : 0) | (a.relu_mask_in ? EPI_BITS_IN : 0) |
+                         (a.ref ? EPI_REF_IN : 0) | (a.relu_mask_out ? EPI_MASK_OUT : 0);
+        switch (kind) {
+        case EPI_PLAIN: return launch_conv_x6s_epi<G, PL, EPI_PLAIN>(a, ntiles, st);
+        case EPI_RELU: return launch_conv_x6s_epi<G, PL, EPI_RELU>(a, ntiles, st);
+        case EPI_RELU | EPI_MASK_OUT: return launch_conv_x6s_epi<G, PL, EPI_RELU | EPI_MASK_OUT>(a, ntiles, st);
+        case EPI_STATS: return launch_conv_x6s_epi<G, PL, EPI_STATS>(a, ntiles, st);
+        case EPI_BITS_IN: return launch_conv_x6s_epi<G, PL, EPI_BITS_IN>(a, ntiles, st);
+        case EPI_REF_IN: return launch_conv_x6s_epi<G, PL, EPI_REF_IN>(a, ntiles, st);
+        default: break;
+        }
+    }
+    return launch_conv_x6s_epi<G, PL, EPI_GENERIC>(a, ntiles, st);
 }
 
 template <int PL>
@@ -1769,9 +1819,11 @@ static int launch_conv_split(int np, const ConvArgs &a, long long ntiles, hipStr
 static int conv_split_impl(const char *who, int planes, const float *in, int cs_in, int K, const void *packed,
                            const float *bias, int N, float *out, int cs_out, int N_store, int out_shift, int vh,
                            int vw, int B, int H, int W, int relu, const float *relu_ref, int cs_ref,
-                           const float *in_amax, float *out_amax, double *bn_partial, void *stream)
+                           const float *in_amax, float *out_amax, double *bn_partial, void *stream,
+                           unsigned *relu_mask_out = nullptr, const unsigned *relu_mask_in = nullptr)
 {
     MMLF_CHECK_ARG(in && packed && out, "%s: null pointer", who);
+    MMLF_CHECK_ARG(!(relu_ref && relu_mask_in), "%s: relu_ref and relu_mask_in are alternatives", who);
     MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0, "%s: bad shape B=%d H=%d W=%d", who, B, H, W);
     MMLF_CHECK_ARG(cs_in > 0 && cs_in % 8 == 0, "%s: cs_in=%d must be a multiple of 8", who, cs_in);
     MMLF_CHECK_ARG(K > 0 && (K + 7) / 8 * 8 == cs_in, "%s: K=%d does not match cs_in=%d", who, K, cs_in);
@@ -1789,6 +1841,7 @@ static int conv_split_impl(const char *who, int planes, const float *in, int cs_
     a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
     a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
     a.in_amax = in_amax; a.out_amax = out_amax; a.bn_partial = bn_partial;
+    a.relu_mask_out = relu_mask_out; a.relu_mask_in = relu_mask_in;
     MMLF_CHECK_ARG(!bn_partial || (planes == 2 && N_store >= N), "%s: BatchNorm statistics need the f16 split path", who);
     // the f16-packed filter ends with its columns' unscale factors
     a.w_unscale = planes == 2 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed) +
@@ -1841,10 +1894,18 @@ extern "C" int mmlf_pack_filter_h2(const float *w, void *packed, int Cout, int C
 extern "C" int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
                                float *out, int cs_out, int N_store, int out_shift, int vh, int vw, int B, int H,
                                int W, int relu, const float *relu_ref, int cs_ref, const float *in_amax,
-                               float *out_amax, double *bn_partial, void *stream)
+                               float *out_amax, double *bn_partial, uint32_t *relu_mask_out,
+                               const uint32_t *relu_mask_in, void *stream)
 {
     return conv_split_impl("mmlf_conv2x2_h2", 2, in, cs_in, K, packed, bias, N, out, cs_out, N_store, out_shift, vh,
-                           vw, B, H, W, relu, relu_ref, cs_ref, in_amax, out_amax, bn_partial, stream);
+                           vw, B, H, W, relu, relu_ref, cs_ref, in_amax, out_amax, bn_partial, stream, relu_mask_out,
+                           relu_mask_in);
+}
+
+extern "C" int64_t mmlf_relu_mask_words(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return -1;
+    return make_grid(B, H, W).NQpad / MMLF_TILE * 4096;        // [tile][8 waves][8 rows][64 lanes]
 }
 
 extern "C" int mmlf_conv2x2_blocks(int N, int B, int H, int W)

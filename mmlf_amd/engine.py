@@ -43,6 +43,11 @@ class Geometry:
         call('mmlf_zero_slack', ptr(t), cs, self.B, self.H, self.W, ptr(t.absmax), _lib.stream_ptr())
         return t
 
+    def relu_mask(self, device):
+        """words for the bit form of one layer's ReLU mask (mmlf_conv2x2_h2 relu_mask_out / relu_mask_in)"""
+        n = int(_lib.load().mmlf_relu_mask_words(self.B, self.H, self.W))
+        return torch.empty(n, dtype=torch.int32, device=device)
+
     def amax_of(self, t, cs):
         """amax array of a grid tensor that did not come from buf() (tests, tools): computed with torch ops."""
         rows = t[:self.NQ * cs].view(self.B * self.R, self.P * cs).abs().amax(1)
@@ -152,9 +157,11 @@ def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace
 
 
 def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0,
-         n_store=None, out_off=0, bn_partial=None):
+         n_store=None, out_off=0, bn_partial=None, mask_out=None, mask_in=None):
     """bn_partial (f16x3 only): a float64 buffer that receives per-workgroup sums of the output and its
-    square per channel -- BatchNorm's training statistics without another pass over the output."""
+    square per channel -- BatchNorm's training statistics without another pass over the output.
+    mask_out / mask_in (f16x3 only): the ReLU mask of the output as bits (Geometry.relu_mask), written by the
+    forward launch and read by the data gradient of the layer above instead of `ref`."""
     prof = PROFILE is not None and K >= 256 and N >= 256
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -163,7 +170,8 @@ def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu
             cs_out if n_store is None else n_store, out_shift, vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref)
     if CONV_MODE == 'f16x3':
         ax = _amax_of(geo, x, cs_in)
-        call('mmlf_conv2x2_h2', *args, ptr(ax), ptr(getattr(out, 'absmax', None)), ptr(bn_partial), _lib.stream_ptr())
+        call('mmlf_conv2x2_h2', *args, ptr(ax), ptr(getattr(out, 'absmax', None)), ptr(bn_partial), ptr(mask_out),
+             ptr(mask_in), _lib.stream_ptr())
     else:
         call('mmlf_conv2x2_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2', *args, _lib.stream_ptr())
     if prof:
@@ -208,7 +216,8 @@ class Trunk:
         w2, b2 = p[f'{spec.prefix}.2.weight'], p[f'{spec.prefix}.2.bias']
         pk1 = pack_filter(w1, var, False)
         y = geo.buf(cs_mid, dev)
-        conv(geo, x, cs_x, spec.cin, pk1, b1, cmid, y, cs_mid, 0, H + 1, W + 1, True)
+        ymask = geo.relu_mask(dev) if (rec_list is not None and CONV_MODE == 'f16x3') else None
+        conv(geo, x, cs_x, spec.cin, pk1, b1, cmid, y, cs_mid, 0, H + 1, W + 1, True, mask_out=ymask)
         if spec.bn and not train and rec_list is None:   # rec_list is None when nothing is saved for backward
             # inference: BatchNorm(eval) is a per-channel affine map -> fold it into conv2 and fuse the ReLU
             C = spec.cout
@@ -233,7 +242,7 @@ class Trunk:
         fused_stats = spec.bn and train and CONV_MODE == 'f16x3'      # statistics from the conv epilogue
         conv(geo, y, cs_mid, cmid, pk2, b2, cmid, z, cs_mid, P + 1, H, W, False,
              bn_partial=ws.partial if fused_stats else None)
-        rec = {'spec': spec, 'var': var, 'x': x, 'cs_x': cs_x, 'y': y, 'z': z}
+        rec = {'spec': spec, 'var': var, 'x': x, 'cs_x': cs_x, 'y': y, 'z': z, 'ymask': ymask}
         if not spec.bn:
             if rec_list is not None:
                 rec_list.append(rec)
@@ -343,7 +352,10 @@ class Trunk:
               ws.wgrad_ws(geo, C, C))
         pk = pack_filter(w2, var, True)
         dy = geo.buf(cs_mid, dev)
-        conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
+        if rec.get('ymask') is not None and CONV_MODE == 'f16x3':
+            conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, mask_in=rec['ymask'])
+        else:
+            conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
         del dz
         # conv1 (pad 1)
         if overlap and need_dx:

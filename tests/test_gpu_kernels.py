@@ -394,7 +394,7 @@ def test_fused_batchnorm_statistics_match_the_two_pass_form(cin, cout):
     nblk = int(_lib.load().mmlf_conv2x2_blocks(cout, B, H, W))
     partial = torch.full((nblk * 2 * cout + 8,), float('nan'), dtype=torch.float64, device=dev)
     call('mmlf_conv2x2_h2', ptr(x), cs_in, cin, ptr(pk), ptr(bias), cout, ptr(z), cs_out, cs_out, geo.P + 1, H, W,
-         B, H, W, 0, None, 0, ptr(amax), ptr(z.absmax), ptr(partial), _lib.stream_ptr())
+         B, H, W, 0, None, 0, ptr(amax), ptr(z.absmax), ptr(partial), None, None, _lib.stream_ptr())
     gamma, beta = torch.rand(cout, device=dev) + 0.5, torch.rand(cout, device=dev) - 0.5
     out = {}
     for mode in ('fused', 'two_pass'):
@@ -428,3 +428,42 @@ def test_slack_and_amax_zeroing():
     assert (v[(geo.P + 1) * cs:geo.NQ * cs] == 3.0).all()
     assert not amax[:geo.amax_n].any() and (amax[geo.amax_n:] == 5.0).all()
     call('mmlf_zero_slack', ptr(buf), cs, B, H, W, None, _lib.stream_ptr())      # the amax array is optional
+
+
+@pytest.mark.parametrize('cin,cout', [(280, 280), (70, 70), (27, 70)])
+def test_relu_bit_mask_replaces_the_activation_reference(cin, cout):
+    """The forward convolution leaves (out > 0) as bits (relu_mask_out); the data gradient of the layer above reads
+    them (relu_mask_in) instead of the activations (relu_ref): both forms of nn.ReLU's backward must give the same
+    gradient bit for bit, on a grid with ragged tiles."""
+    from mmlf_amd import engine
+    dev = _dev()
+    B, H, W = 3, 21, 35
+    geo = engine.Geometry(B, H, W)
+    cs_in, cs_mid = engine.cs_of(cin), engine.cs_of(cout)
+    gen = torch.Generator(device=dev).manual_seed(cin)
+
+    def grid(cs, c, h, w, off):
+        t = geo.buf(cs, dev)
+        v = t[:geo.NQ * cs].view(B, geo.R, geo.P, cs)
+        v.zero_()
+        v[:, off:off + h, off:off + w, :c] = torch.rand((B, h, w, c), device=dev, generator=gen) - 0.5
+        t.absmax = geo.amax_of(t, cs)
+        return t
+
+    x = grid(cs_in, cin, H, W, 1)
+    w1 = (torch.rand((cout, cin, 2, 2), device=dev, generator=gen) - 0.5) * 0.2
+    b1 = torch.rand(cout, device=dev, generator=gen) - 0.5
+    y, mask = geo.buf(cs_mid, dev), geo.relu_mask(dev)
+    mask.fill_(-1)
+    engine.conv(geo, x, cs_in, cin, engine.pack_filter(w1, 0, False), b1, cout, y, cs_mid, 0, H + 1, W + 1, True, mask_out=mask)
+    frac = float((y[:geo.NQ * cs_mid] > 0).float().mean())
+    assert 0.05 < frac < 0.6                       # a real mix of kept and dropped elements
+    w2 = (torch.rand((cout, cout, 2, 2), device=dev, generator=gen) - 0.5) * 0.2
+    dz = grid(cs_mid, cout, H, W, 1)
+    pk = engine.pack_filter(w2, 0, True)
+    a, b = geo.buf(cs_mid, dev), geo.buf(cs_mid, dev)
+    engine.conv(geo, dz, cs_mid, cout, pk, None, cout, a, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
+    engine.conv(geo, dz, cs_mid, cout, pk, None, cout, b, cs_mid, 0, H + 1, W + 1, False, mask_in=mask)
+    assert torch.equal(a, b)
+    assert torch.equal(a.absmax, b.absmax)
+    assert float(a.abs().max()) > 0

@@ -54,11 +54,17 @@ def run(cin, cout):
     fl0 = 2.0 * B * H * W * cout * 4 * cin
     res = {}
     res['fwd_p1'] = (timeit(lambda: engine.conv(geo, x, cs_in, cin, pk, b, cout, out1, cs_out, 0, H + 1, W + 1, True)), fl1)
+    if NEW and hasattr(geo, 'relu_mask'):
+        mask = geo.relu_mask(dev)
+        res['fwd_p1_mask'] = (timeit(lambda: engine.conv(geo, x, cs_in, cin, pk, b, cout, out1, cs_out, 0, H + 1, W + 1, True, mask_out=mask)), fl1)
     res['fwd_p0_stats'] = (timeit(lambda: engine.conv(geo, y, cs_out, cout, pk, b, cout, out0, cs_out, geo.P + 1, H, W, False,
                                                         bn_partial=ws.partial)), fl0)
     g0 = grid_rand(cs_out, cout, H, W, 1)                     # dz
     res['dgrad_p0_ref'] = (timeit(lambda: engine.conv(geo, g0, cs_out, cout, pkd, None, cin, out1, cs_in, 0, H + 1, W + 1, False,
                                                        ref=y, cs_ref=cs_out)), fl1)
+    if NEW and hasattr(geo, 'relu_mask'):
+        res['dgrad_p0_bits'] = (timeit(lambda: engine.conv(geo, g0, cs_out, cout, pkd, None, cin, out1, cs_in, 0, H + 1, W + 1, False,
+                                                            mask_in=mask)), fl1)
     g1 = grid_rand(cs_out, cout, H + 1, W + 1, 0)             # dy
     res['dgrad_p1'] = (timeit(lambda: engine.conv(geo, g1, cs_out, cout, pkd, None, cin, out0, cs_in, geo.P + 1, H, W, False)), fl0)
     gw, gb = torch.zeros_like(w), torch.zeros(cout, device=dev)
