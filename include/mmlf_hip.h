@@ -109,6 +109,21 @@ int64_t mmlf_relu_mask_words(int B, int H, int W);
 /* number of workgroups mmlf_conv2x2_h2 launches for this shape (= rows of bn_partial) */
 int mmlf_conv2x2_blocks(int N, int B, int H, int W);
 
+/* "Thin" convolution: N <= 2 output channels over a wide input (first convolution of the BASE / UPR head,
+ * feed_forward.py:179-182): a matrix-vector product bound by reading the input once, evaluated with plain float32
+ * FMAs straight from the OIHW master filter (no packing, no operand split, any MMLF_CONV_MODE).  Same semantics as
+ * mmlf_conv2x2 for the written extent: every position of the output grid is written (zeros outside the valid
+ * extent and in the pad channels), the output's amax array is raised.  workspace:
+ * mmlf_conv2x2_thin_workspace_floats(B,H,W) floats; the weight gradient's: mmlf_conv2x2_wgrad_thin_workspace_floats(Cin). */
+int64_t mmlf_conv2x2_thin_workspace_floats(int B, int H, int W);
+int mmlf_conv2x2_thin(const float *in, int cs_in, int K, const float *w_oihw, const float *bias, int N,
+                      float *out, int cs_out, int out_shift, int vh, int vw, int B, int H, int W, int relu,
+                      int variant, float *workspace, float *out_amax, void *stream);
+int64_t mmlf_conv2x2_wgrad_thin_workspace_floats(int Cin);
+int mmlf_conv2x2_wgrad_thin(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout, int g_shift,
+                            float *gw_oihw, float *gb, int variant, int accumulate, float *workspace,
+                            int B, int H, int W, void *stream);
+
 /* Weight + bias gradient of the convolution above (autograd of feed_forward.py:123,125 reached
  * from train/cli.py:257):  gw[co][ci][tap] (+)= sum_q in[q + off_t][ci] * g[q + g_shift][co],
  * gb[co] (+)= sum_q g[q + g_shift][co].  g must be zero outside its stored extent.

@@ -33,6 +33,10 @@ SIGNATURES = {
     'mmlf_pack_filter_h2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_conv2x2_h2': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mmlf_relu_mask_words': (_i64, [_i, _i, _i]),
+    'mmlf_conv2x2_thin_workspace_floats': (_i64, [_i, _i, _i]),
+    'mmlf_conv2x2_thin': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'mmlf_conv2x2_wgrad_thin_workspace_floats': (_i64, [_i]),
+    'mmlf_conv2x2_wgrad_thin': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     'mmlf_conv2x2_blocks': (_i, [_i, _i, _i, _i]),
     'mmlf_bn_stats_finalize': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mmlf_conv2x2_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),

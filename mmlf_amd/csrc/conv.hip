@@ -1915,3 +1915,260 @@ extern "C" int mmlf_conv2x2_blocks(int N, int B, int H, int W)
     const Grid g = make_grid(B, H, W);
     return (int)conv_split_blocks(np / 16, g.NQpad / MMLF_TILE);
 }
+
+// ---------------------------------------------------------------------------------------------
+// "thin" convolutions: N <= 2 output channels over a wide input (the first convolution of the BASE / UPR head,
+// reference feed_forward.py:179-182: 280 -> 1 | 2).  On the MFMA kernels such a layer pays for 32 columns to
+// use one or two and runs for 2.9 ms forward and 6.3 ms in the weight gradient at bs=512; it is a matrix-VECTOR
+// product, bound by reading the input once: plain float32 FMAs (no operand split), one wave per grid position.
+//   forward : part[p][t][o] = sum_c in[p][c] * W[o][c][tap t]        (thin_rowdot_kernel, reads `in` once)
+//             out[q + shift][o] = valid(q) ? act(b[o] + sum_t part[q + off_t][t][o]) : 0   (thin_combine_kernel)
+//   weights : dW[o][c][t] += sum_p in[p][c] * g[p - off_t + g_shift][o]                    (thin_wgrad_kernel)
+// ---------------------------------------------------------------------------------------------
+#define THIN_MAXN 2
+struct ThinArgs {
+    const float *in;          // grid tensor, channel stride cs_in (multiple of 4), C real channels
+    const float *w;           // OIHW master (N, C, 2, 2)
+    const float *bias;
+    float *part;              // [positions][4 taps][THIN_MAXN]
+    float *out;
+    float *out_amax;
+    const float *g;           // wgrad: output gradient, channel stride cs_g
+    float *wpart;             // wgrad partial sums [split][4][CIP][THIN_MAXN]
+    long long NQ, npos;       // valid grid positions; positions to visit (NQ + P + 1 for the forward halo)
+    int cs_in, C, N, cs_out, out_shift, vh, vw, P, R, relu, variant, cs_g, g_shift, CIP, dgrad_taps;
+    Magic divP, divR;
+};
+
+// A wave takes 64 consecutive positions.  Channels go through LDS in slices of 32: the slice is read from global
+// memory in whole 128-byte row segments (lane = (row, float4)), and consumed with lane = position, so the dot
+// products need no cross-lane reduction (eight of them per position through ds_bpermute made this kernel LDS-bound);
+// the filter values of a slice are wave-uniform and come through the scalar cache.
+__global__ __launch_bounds__(256) void thin_rowdot_kernel(ThinArgs a)
+{
+    __shared__ float tile[4][64][33];                     // [wave][position][channel of the slice] (+1: conflict-free columns)
+    __shared__ float4 wt[4][32][2];                       // [wave][channel of the slice][o] = the four taps of W[o][c]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wv));
+    const long long nwaves = gridDim.x * 4ll;
+    const int nslice = (a.C + 31) / 32;
+    for (long long p0 = 64 * wave; p0 < a.npos; p0 += 64 * nwaves) {
+        float acc[4][THIN_MAXN];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < THIN_MAXN; ++o) acc[t][o] = 0.f;
+        for (int sl = 0; sl < nslice; ++sl) {
+            // 64 rows x 8 float4: lane (r8 = lane >> 3, f = lane & 7) loads rows r8, r8 + 8, ...
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = (lane >> 3) + 8 * j, f = lane & 7;
+                const long long p = p0 + r < a.npos ? p0 + r : a.npos - 1;
+                const int c = 32 * sl + 4 * f;
+                v[j] = *reinterpret_cast<const float4 *>(a.in + (size_t)p * a.cs_in + (c < a.cs_in ? c : 0));
+                if (c >= a.cs_in) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            {   // this slice's filter values: lane (c = lane & 31, o = lane >> 5), taps in packed order
+                const int c = 32 * sl + (lane & 31), o = lane >> 5;
+                float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < a.C && o < a.N) {
+                    const float *wp = a.w + ((size_t)o * a.C + c) * 4;
+                    w4 = make_float4(wp[master_tap(0, a.variant)], wp[master_tap(1, a.variant)], wp[master_tap(2, a.variant)],
+                                     wp[master_tap(3, a.variant)]);
+                }
+                wt[wv][lane & 31][o] = w4;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = (lane >> 3) + 8 * j, f = lane & 7;
+                tile[wv][r][4 * f + 0] = v[j].x; tile[wv][r][4 * f + 1] = v[j].y;
+                tile[wv][r][4 * f + 2] = v[j].z; tile[wv][r][4 * f + 3] = v[j].w;
+            }
+            // (one wave reads what it wrote: program order + the compiler's lgkmcnt waits suffice)
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {                // channels past C carry zero weights
+                const float x = tile[wv][lane][k];
+                const float4 w0 = wt[wv][k][0], w1 = wt[wv][k][1];
+                acc[0][0] = fmaf(x, w0.x, acc[0][0]); acc[1][0] = fmaf(x, w0.y, acc[1][0]);
+                acc[2][0] = fmaf(x, w0.z, acc[2][0]); acc[3][0] = fmaf(x, w0.w, acc[3][0]);
+                acc[0][1] = fmaf(x, w1.x, acc[0][1]); acc[1][1] = fmaf(x, w1.y, acc[1][1]);
+                acc[2][1] = fmaf(x, w1.z, acc[2][1]); acc[3][1] = fmaf(x, w1.w, acc[3][1]);
+            }
+        }
+        const long long p = p0 + lane;
+        if (p < a.npos) {
+            float4 *dst = reinterpret_cast<float4 *>(a.part + (size_t)p * 4 * THIN_MAXN);
+            dst[0] = make_float4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+            dst[1] = make_float4(acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+        }
+    }
+}
+
+// one workgroup per DESTINATION grid row: writes every position of the row (zeros outside the valid extent)
+__global__ __launch_bounds__(128) void thin_combine_kernel(ThinArgs a)
+{
+    const int drow = blockIdx.x;                          // global grid row of the destination
+    float mx = 0.f;
+    for (int x = threadIdx.x; x < a.P; x += blockDim.x) {
+        const long long d = (long long)drow * a.P + x, q = d - a.out_shift;
+        float v[THIN_MAXN] = {0.f, 0.f};
+        bool valid = false;
+        if (q >= 0 && q < a.NQ) {
+            const unsigned row = fastdiv((unsigned)q, a.divP);
+            const int qx = (int)(q - (long long)row * a.P), qy = (int)(row - fastdiv(row, a.divR) * a.R);
+            valid = qy < a.vh && qx < a.vw;
+        }
+        if (valid) {
+            const int offs[4] = {0, 1, a.P, a.P + 1};
+#pragma unroll
+            for (int o = 0; o < THIN_MAXN; ++o) {
+                float s = (a.bias && o < a.N) ? a.bias[o] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) s += a.part[((size_t)(q + offs[t]) * 4 + t) * THIN_MAXN + o];
+                if (a.relu) s = fmaxf(s, 0.f);
+                v[o] = o < a.N ? s : 0.f;
+            }
+        }
+        float *dst = a.out + (size_t)d * a.cs_out;
+        for (int o = 0; o < a.cs_out; ++o) dst[o] = o < THIN_MAXN ? v[o] : 0.f;
+        mx = fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    }
+    if (a.out_amax) mmlf_amax_update_row(mx, a.out_amax, drow);
+}
+
+extern "C" int64_t mmlf_conv2x2_thin_workspace_floats(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return -1;
+    const Grid g = make_grid(B, H, W);
+    return (g.NQ + g.P + 2) * 4 * THIN_MAXN;
+}
+
+extern "C" int mmlf_conv2x2_thin(const float *in, int cs_in, int K, const float *w_oihw, const float *bias, int N,
+                                 float *out, int cs_out, int out_shift, int vh, int vw, int B, int H, int W, int relu,
+                                 int variant, float *workspace, float *out_amax, void *stream)
+{
+    MMLF_CHECK_ARG(in && w_oihw && out && workspace, "mmlf_conv2x2_thin: null pointer");
+    MMLF_CHECK_ARG(N >= 1 && N <= THIN_MAXN && K >= 1 && K <= cs_in && cs_in % 4 == 0 && cs_in <= 512,
+                   "mmlf_conv2x2_thin: N=%d K=%d cs_in=%d (N <= 2, cs_in <= 512)", N, K, cs_in);
+    MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0 && cs_out >= THIN_MAXN && variant >= 0 && variant <= 2, "mmlf_conv2x2_thin: bad shape");
+    const Grid g = make_grid(B, H, W);
+    MMLF_CHECK_ARG(out_shift >= 0 && out_shift <= g.P + 1 && g.NQpad + 2 * g.P + 64 < (1ll << 31), "mmlf_conv2x2_thin: out_shift / size");
+    ThinArgs a = {};
+    a.in = in; a.w = w_oihw; a.bias = bias; a.part = workspace; a.out = out; a.out_amax = out_amax;
+    a.NQ = g.NQ; a.npos = g.NQ + g.P + 2; a.cs_in = cs_in; a.C = K; a.N = N; a.cs_out = cs_out; a.out_shift = out_shift;
+    a.vh = vh; a.vw = vw; a.P = g.P; a.R = g.R; a.relu = relu; a.variant = variant;
+    a.divP = make_magic((unsigned)g.P); a.divR = make_magic((unsigned)g.R);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(thin_rowdot_kernel, dim3(4 * device_cus()), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(thin_combine_kernel, dim3((unsigned)(B * g.R)), dim3(128), 0, st, a);
+    return mmlf_launch_status("mmlf_conv2x2_thin");
+}
+
+// weight + bias gradient of a thin convolution: wave-private sums over its positions, reduced by wgrad_reduce_kernel.
+// Four positions per iteration with every load issued up front (the loop is latency-bound otherwise); the wave index
+// is made scalar so that the gradients -- the same address for all lanes -- come in through the scalar cache.
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(ThinArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const long long nwaves = gridDim.x * 4ll;
+    float acc[2][4][THIN_MAXN][4];                        // [half][tap][o][channel of the float4]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < THIN_MAXN; ++o)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[h][t][o][k] = 0.f;
+    float gsum[THIN_MAXN] = {0.f, 0.f};
+    const bool first = 4 * lane < a.cs_in, second = 256 + 4 * lane < a.cs_in;
+    const int offs[4] = {0, 1, a.P, a.P + 1};
+    constexpr int U = 4;
+    // a wave owns runs of U consecutive positions: p0 = U * (wave + k * nwaves)
+    for (long long p0 = U * wave; p0 < a.npos; p0 += U * nwaves) {
+        float4 x0[U], x1[U];
+        float gt[U][4][THIN_MAXN];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long p = p0 + u < a.npos ? p0 + u : a.npos - 1;      // (clamped: its gradients are zeroed below)
+            const float *row = a.in + (size_t)p * a.cs_in;
+            x0[u] = first ? *reinterpret_cast<const float4 *>(row + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x1[u] = second ? *reinterpret_cast<const float4 *>(row + 256 + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // in[p] is tap t's operand of output position p - off_t, whose gradient sits at g[p - off_t + g_shift]
+                const long long q = p0 + u - offs[t];
+                const bool ok = p0 + u < a.npos && q >= 0 && q < a.NQ;
+                // unconditional loads from a clamped position (a select per load would serialise them behind branches);
+                // cs_g >= 2: both columns exist, column 1 is a zero pad channel when N == 1
+                const float2 gv = *reinterpret_cast<const float2 *>(a.g + (size_t)((ok ? q : 0) + a.g_shift) * a.cs_g);
+                gt[u][t][0] = ok ? gv.x : 0.f;
+                gt[u][t][1] = ok ? gv.y : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float xs[2][4] = {{x0[u].x, x0[u].y, x0[u].z, x0[u].w}, {x1[u].x, x1[u].y, x1[u].z, x1[u].w}};
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int o = 0; o < THIN_MAXN; ++o)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[h][t][o][k] = fmaf(xs[h][k], gt[u][t][o], acc[h][t][o][k]);
+#pragma unroll
+            for (int o = 0; o < THIN_MAXN; ++o) gsum[o] += gt[u][0][o];    // tap 0: every gradient position once
+        }
+    }
+    float *pp = a.wpart + (size_t)wave * 4 * a.CIP * THIN_MAXN;           // [tap][ci][o]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = 256 * h + 4 * lane + k;
+                if (c < a.C)
+#pragma unroll
+                    for (int o = 0; o < THIN_MAXN; ++o) pp[((size_t)t * a.CIP + c) * THIN_MAXN + o] = acc[h][t][o][k];
+            }
+    if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < THIN_MAXN; ++o) pp[((size_t)t * a.CIP + a.C) * THIN_MAXN + o] = t == 0 ? gsum[o] : 0.f;   // bias row
+    }
+}
+
+static int thin_wgrad_waves() { return 4 * 4 * device_cus(); }
+
+extern "C" int64_t mmlf_conv2x2_wgrad_thin_workspace_floats(int Cin)
+{
+    if (Cin <= 0) return -1;
+    return (int64_t)thin_wgrad_waves() * 4 * (Cin + 1) * THIN_MAXN;
+}
+
+extern "C" int mmlf_conv2x2_wgrad_thin(const float *in, int cs_in, int Cin, const float *g, int cs_g, int Cout, int g_shift,
+                                       float *gw_oihw, float *gb, int variant, int accumulate, float *workspace, int B,
+                                       int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(in && g && gw_oihw && workspace, "mmlf_conv2x2_wgrad_thin: null pointer");
+    MMLF_CHECK_ARG(Cout >= 1 && Cout <= THIN_MAXN && Cout <= cs_g && Cin >= 1 && Cin <= cs_in && cs_in % 4 == 0 && cs_in <= 512,
+                   "mmlf_conv2x2_wgrad_thin: Cin=%d Cout=%d cs_in=%d", Cin, Cout, cs_in);
+    MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0 && variant >= 0 && variant <= 2, "mmlf_conv2x2_wgrad_thin: bad shape");
+    const Grid gr = make_grid(B, H, W);
+    MMLF_CHECK_ARG(g_shift >= 0 && g_shift <= gr.P + 1, "mmlf_conv2x2_wgrad_thin: g_shift=%d", g_shift);
+    ThinArgs a = {};
+    a.in = in; a.g = g; a.wpart = workspace; a.NQ = gr.NQ; a.npos = gr.NQ + gr.P + 2;
+    a.cs_in = cs_in; a.C = Cin; a.N = Cout; a.cs_g = cs_g; a.g_shift = g_shift; a.P = gr.P; a.CIP = Cin + 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int nwaves = thin_wgrad_waves();
+    hipLaunchKernelGGL(thin_wgrad_kernel, dim3(nwaves / 4), dim3(256), 0, st, a);
+    const int total = 4 * (Cin + 1) * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw_oihw, gb, Cin, Cout,
+                       Cin + 1, THIN_MAXN, nwaves, variant, accumulate);
+    return mmlf_launch_status("mmlf_conv2x2_wgrad_thin");
+}

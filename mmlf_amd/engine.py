@@ -78,6 +78,14 @@ class _Workspace:
         self.side = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
         self.partial = torch.empty(2 * 512 * max(BN_BLOCKS, LOSS_BLOCKS) + 8, dtype=torch.float64, device=device)
 
+    def scratch(self, name, n):
+        """a float32 scratch buffer of at least n elements, reused across calls of this thread on this stream"""
+        t = getattr(self, name, None)
+        if t is None or t.numel() < n:
+            t = torch.empty(n, dtype=torch.float32, device=self.device)
+            setattr(self, name, t)
+        return t
+
     def wgrad_ws(self, geo, cin, cout, side=False):
         n = int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout, geo.B, geo.H, geo.W))
         if n < 0:
@@ -145,8 +153,17 @@ CHECK_ABSMAX = bool(os.environ.get('MMLF_CHECK_ABSMAX'))
 OVERLAP_WGRAD = os.environ.get('MMLF_OVERLAP_WGRAD', '1') != '0'
 
 
+THIN_MAX_N, THIN_MIN_K = 2, 64     # mmlf_conv2x2_thin: at most 2 output channels over at least 64 input channels
+
+
 def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace):
     """weight + bias gradient, accumulated into gw / gb"""
+    if cout <= THIN_MAX_N and cin >= THIN_MIN_K and cs_in <= 512:
+        # a matrix-vector product (the BASE / UPR head): plain float32 FMAs, bound by reading x once
+        ws = _Workspace.get(x.device).scratch('thin_wgrad', int(_lib.load().mmlf_conv2x2_wgrad_thin_workspace_floats(cin)))
+        call('mmlf_conv2x2_wgrad_thin', ptr(x), cs_in, cin, ptr(g), cs_g, cout, g_shift, ptr(gw), ptr(gb), variant, 1,
+             ptr(ws), geo.B, geo.H, geo.W, _lib.stream_ptr())
+        return
     args = (ptr(x), cs_in, cin, ptr(g), cs_g, cout, g_shift, ptr(gw), ptr(gb), variant, 1, ptr(workspace),
             geo.B, geo.H, geo.W)
     if CONV_MODE == 'f16x3':
@@ -157,11 +174,18 @@ def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace
 
 
 def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0,
-         n_store=None, out_off=0, bn_partial=None, mask_out=None, mask_in=None):
+         n_store=None, out_off=0, bn_partial=None, mask_out=None, mask_in=None, w_master=None, variant=0):
     """bn_partial (f16x3 only): a float64 buffer that receives per-workgroup sums of the output and its
     square per channel -- BatchNorm's training statistics without another pass over the output.
     mask_out / mask_in (f16x3 only): the ReLU mask of the output as bits (Geometry.relu_mask), written by the
     forward launch and read by the data gradient of the layer above instead of `ref`."""
+    if (w_master is not None and N <= THIN_MAX_N and K >= THIN_MIN_K and cs_in <= 512 and ref is None and mask_in is None
+            and mask_out is None and bn_partial is None and out_off == 0 and n_store in (None, cs_out)):
+        # a matrix-vector product (the BASE / UPR head): straight from the OIHW master filter
+        ws = _Workspace.get(x.device).scratch('thin_fwd', int(_lib.load().mmlf_conv2x2_thin_workspace_floats(geo.B, geo.H, geo.W)))
+        call('mmlf_conv2x2_thin', ptr(x), cs_in, K, ptr(w_master), ptr(bias), N, ptr(out), cs_out, out_shift, vh, vw,
+             geo.B, geo.H, geo.W, int(relu), variant, ptr(ws), ptr(getattr(out, 'absmax', None)), _lib.stream_ptr())
+        return
     prof = PROFILE is not None and K >= 256 and N >= 256
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -216,8 +240,10 @@ class Trunk:
         w2, b2 = p[f'{spec.prefix}.2.weight'], p[f'{spec.prefix}.2.bias']
         pk1 = pack_filter(w1, var, False)
         y = geo.buf(cs_mid, dev)
-        ymask = geo.relu_mask(dev) if (rec_list is not None and CONV_MODE == 'f16x3') else None
-        conv(geo, x, cs_x, spec.cin, pk1, b1, cmid, y, cs_mid, 0, H + 1, W + 1, True, mask_out=ymask)
+        thin = cmid <= THIN_MAX_N and spec.cin >= THIN_MIN_K        # the head: matrix-vector kernels, y is tiny
+        ymask = geo.relu_mask(dev) if (rec_list is not None and CONV_MODE == 'f16x3' and not thin) else None
+        conv(geo, x, cs_x, spec.cin, pk1, b1, cmid, y, cs_mid, 0, H + 1, W + 1, True, mask_out=ymask, w_master=w1,
+             variant=var)
         if spec.bn and not train and rec_list is None:   # rec_list is None when nothing is saved for backward
             # inference: BatchNorm(eval) is a per-channel affine map -> fold it into conv2 and fuse the ReLU
             C = spec.cout

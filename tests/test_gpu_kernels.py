@@ -467,3 +467,56 @@ def test_relu_bit_mask_replaces_the_activation_reference(cin, cout):
     assert torch.equal(a, b)
     assert torch.equal(a.absmax, b.absmax)
     assert float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize('cin,cout', [(280, 1), (280, 2), (70, 2)])
+@pytest.mark.parametrize('pad', [1, 0])
+@pytest.mark.parametrize('variant', [0, 2])
+def test_thin_convolution_and_weight_gradient(oracle, cin, cout, pad, variant):
+    """mmlf_conv2x2_thin / mmlf_conv2x2_wgrad_thin (the BASE / UPR head's 280 -> 1 | 2 convolution as a
+    matrix-vector product) against the oracle: forward with bias + ReLU, zero border, amax rows; weight and bias
+    gradient accumulated on top of a known value."""
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    from tests_helpers import variant_filter
+    dev = _dev()
+    rs = np.random.RandomState(cin + 10 * cout + pad + variant)
+    B, H, W = 3, 9, 37
+    geo = engine.Geometry(B, H, W)
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    w = rs.uniform(-0.5, 0.5, (cout, cin, 2, 2)).astype(np.float32)
+    b = rs.uniform(-0.5, 0.5, (cout,)).astype(np.float32)
+    ih, iw, ioff = (H, W, 1) if pad == 1 else (H + 1, W + 1, 0)
+    oh, ow, ooff = (H + 1, W + 1, 0) if pad == 1 else (H, W, 1)
+    shift = 0 if pad == 1 else geo.P + 1
+    x = rs.uniform(-1, 1, (B, cin, ih, iw)).astype(np.float32)
+    wv = variant_filter(w, variant)
+    ref = oracle.conv2x2(x, wv, b, pad, relu=True)
+    xg = torch.from_numpy(grid_from_nchw(x, cs_in, geo, offset=ioff)).to(dev)
+    out = geo.buf(cs_out, dev)
+    out.fill_(float('nan'))
+    out.absmax.zero_()
+    ws = torch.empty(int(_lib.load().mmlf_conv2x2_thin_workspace_floats(B, H, W)), device=dev)
+    tw, tb = torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)       # (kept alive: the call takes raw pointers)
+    call('mmlf_conv2x2_thin', ptr(xg), cs_in, cin, ptr(tw), ptr(tb), cout,
+         ptr(out), cs_out, shift, oh, ow, B, H, W, 1, variant, ptr(ws), ptr(out.absmax), _lib.stream_ptr())
+    full = out.cpu().numpy().reshape(geo.alloc, cs_out)
+    got, g = nchw_from_grid(full.reshape(-1), cs_out, cout, geo, oh, ow, ooff)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+    g2 = g.copy()
+    g2[:, ooff:ooff + oh, ooff:ooff + ow, :cout] = 0
+    assert not g2.any() and np.isfinite(full[:geo.NQ]).all()          # zero border and pad channels, everything written
+    assert torch.equal(out.absmax, geo.amax_of(torch.nan_to_num(out), cs_out))
+    # the engine routes this shape to the thin kernel in every conv mode
+    out2 = geo.buf(cs_out, dev)
+    engine.conv(geo, xg, cs_in, cin, None, tb, cout, out2, cs_out, shift, oh, ow, True, w_master=tw, variant=variant)
+    assert torch.equal(out2[:geo.NQ * cs_out], out[:geo.NQ * cs_out])
+    # weight / bias gradient
+    go = rs.uniform(-1, 1, (B, cout, oh, ow)).astype(np.float32)
+    _, gw_v, gb = oracle.conv2x2_bwd(x, wv, go, pad)
+    gw = variant_filter(gw_v, variant, inverse=True)
+    gg = torch.from_numpy(grid_from_nchw(go, cs_out, geo, offset=ooff)).to(dev)
+    tgw, tgb = torch.full((cout, cin, 2, 2), 0.5, device=dev), torch.full((cout,), -0.25, device=dev)
+    engine.wgrad(geo, xg, cs_in, cin, gg, cs_out, cout, shift, tgw, tgb, variant, None)
+    np.testing.assert_allclose(tgw.cpu().numpy() - 0.5, gw, rtol=1e-4, atol=2e-5 * np.abs(gw).max())
+    np.testing.assert_allclose(tgb.cpu().numpy() + 0.25, gb, rtol=1e-4, atol=2e-5 * np.abs(gb).max())
