@@ -52,6 +52,7 @@ struct ConvArgs {
     long long NQ;
     int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
     int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6s_kernel)
+    int a_tail;                          // ... positions the last 64-position piece of a window (segment) has to fetch
     const float *in_amax;                // f16 split: amax array of `in` (common.h): per-wave power-of-two operand scales
     const float *w_unscale;              // f16 split: 1 / (power-of-two scale of packed column n), [NP]
     float *out_amax;                     // optional: amax array of `out` (tensor and grid-row maxima, atomic max)
@@ -515,8 +516,12 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
         const int hf = j >= a.a_pieces, blk = j - hf * a.a_pieces;
         const int pos = 64 * blk + (blk >= 5 ? a.seg_delta : 0);
         a_src[k] = ((unsigned)pos * (unsigned)a.cs_in + 4u * hf) * 4u;
-        a_dst[k] = (unsigned)(hf * A_HALF + 64 * blk) * 16u;
+        // bit 0 marks the last piece of a window (of a segment in two-segment mode): only its first a_tail positions
+        // are ever read, the other lanes re-fetch position a_tail - 1 instead of 64 - a_tail positions nobody uses
+        const bool last = a.seg_delta ? (blk == 4 || blk == 9) : blk == a.a_pieces - 1;
+        a_dst[k] = (unsigned)(hf * A_HALF + 64 * blk) * 16u + (last ? 1u : 0u);
     }
+    const unsigned tail_lim = (unsigned)(a.a_tail - 1) * (unsigned)a.cs_in * 4u;
     const unsigned b_src0 = 1024u * jb0, b_dst0 = (unsigned)(A_F4 + 64 * jb0) * 16u;
 
     // slot 0 = this wave's pieces k < PER_SLOT, slot 1 = the rest; k is a compile-time index
@@ -527,8 +532,9 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
             unsigned vo_, d_;                                                                            \
             if ((k) < nA) {                                                                              \
                 sb_ = in0 + (size_t)(tl) * tile_bytes + 32u * (c) + a_src[(k) < 3 ? (k) : 0];            \
-                vo_ = voff_a;                                                                            \
                 d_ = a_dst[(k) < 3 ? (k) : 0];                                                           \
+                vo_ = min(voff_a, (d_ & 1u) ? tail_lim : 0xffffffffu);                                   \
+                d_ &= ~1u;                                                                               \
             } else {                                                                                     \
                 const unsigned kb_ = 8192u * (unsigned)((k) - nA);                                       \
                 sb_ = wp_base + (size_t)(c) * (B_F4 * 16) + b_src0 + kb_;                                \
@@ -1851,8 +1857,10 @@ static int conv_split_impl(const char *who, int planes, const float *in, int cs_
     MMLF_CHECK_ARG(g.NQpad + g.P + 64 < (1ll << 31), "%s: batch x image too large for 32-bit grid positions", who);
     if (g.P + 257 <= 640) {   // one contiguous window of 257 + P positions
         a.a_pieces = (g.P + 257 + 63) / 64; a.seg_slot = g.P; a.seg_delta = 0;
+        a.a_tail = g.P + 257 - 64 * (a.a_pieces - 1);
     } else {                  // two 320-slot segments: rows y and y+1
         a.a_pieces = 10; a.seg_slot = 320; a.seg_delta = g.P - 320;
+        a.a_tail = 1;         // positions Q0 .. Q0 + 256 of each row
     }
     const long long ntiles = g.NQpad / MMLF_TILE;
     hipStream_t st = (hipStream_t)stream;
