@@ -51,8 +51,8 @@ struct ConvArgs {
     const float *ref;
     long long NQ;
     int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
-    int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6s_kernel)
-    int a_tail;                          // ... positions the last 64-position piece of a window (segment) has to fetch
+    int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6s_kernel): 32-position pieces,
+    int a_per_seg, a_tail;               // ... pieces per segment, positions the last piece of a segment has to fetch
     const float *in_amax;                // f16 split: amax array of `in` (common.h): per-wave power-of-two operand scales
     const float *w_unscale;              // f16 split: 1 / (power-of-two scale of packed column n), [NP]
     float *out_amax;                     // optional: amax array of `out` (tensor and grid-row maxima, atomic max)
@@ -467,12 +467,14 @@ template <int G, int PL, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
 {
     constexpr int NP = G * 16;
-    // A: [channel half(2)][640 slots] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
+    // A: [640 slots][channel half(2)] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
     // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
     // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
     // instead of 2 x 257.  Otherwise two 320-slot segments (rows y and y+1) are loaded.
-    constexpr int A_HALF = 640;
-    constexpr int A_F4 = 2 * A_HALF;
+    // A DMA piece is 32 positions x 32 bytes: lanes 2i, 2i+1 fetch the two 16-byte halves of position i's chunk, ONE
+    // 32-byte sector request for the memory pipeline (half-major pieces of 64 positions asked for every sector twice,
+    // from two instructions; the 70-channel launches are bound by that request rate).
+    constexpr int A_F4 = 2 * 640;
     constexpr int B_F4 = 4 * PL * NP;
     constexpr int BUF_F4 = A_F4 + B_F4;
     constexpr int N_B = B_F4 / 64;
@@ -495,16 +497,16 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
             for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
 
     // DMA addressing: a piece = wave-uniform 64-bit base (SGPRs) + one shared per-lane byte offset
-    const unsigned voff_a = (unsigned)lane * (unsigned)a.cs_in * 4u;   // A pieces: lane = position
+    const unsigned voff_a = ((unsigned)(lane >> 1) * (unsigned)a.cs_in + 4u * (lane & 1)) * 4u;   // A pieces
     const unsigned voff_b = (unsigned)lane * 16u;                      // B pieces: linear
     const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
     const char *in0 = reinterpret_cast<const char *>(a.in);
     const char *wp_base = reinterpret_cast<const char *>(a.wp);
     const size_t tile_bytes = (size_t)MMLF_TILE * a.cs_in * 4;
-    // Piece ownership, fixed for the launch: of the chunk's pieces j = 0 .. 2*a_pieces + N_B - 1 (activation
+    // Piece ownership, fixed for the launch: of the chunk's pieces j = 0 .. a_pieces + N_B - 1 (activation
     // pieces first) wave w issues j = w, w+8, ...: nA activation pieces, then nB weight pieces that are
     // 8 KiB apart in both the packed filter and LDS.  The first half of them goes out in slot 0.
-    const int n_a = 2 * a.a_pieces;
+    const int n_a = a.a_pieces;
     const int nA = (n_a - w + 7) >> 3;
     const int jb0 = w + 8 * nA - n_a;
     const int nB = (N_B - jb0 + 7) >> 3;
@@ -513,15 +515,14 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int j = w + 8 * k;
-        const int hf = j >= a.a_pieces, blk = j - hf * a.a_pieces;
-        const int pos = 64 * blk + (blk >= 5 ? a.seg_delta : 0);
-        a_src[k] = ((unsigned)pos * (unsigned)a.cs_in + 4u * hf) * 4u;
-        // bit 0 marks the last piece of a window (of a segment in two-segment mode): only its first a_tail positions
-        // are ever read, the other lanes re-fetch position a_tail - 1 instead of 64 - a_tail positions nobody uses
-        const bool last = a.seg_delta ? (blk == 4 || blk == 9) : blk == a.a_pieces - 1;
-        a_dst[k] = (unsigned)(hf * A_HALF + 64 * blk) * 16u + (last ? 1u : 0u);
+        const int seg = j >= a.a_per_seg, idx = j - seg * a.a_per_seg;   // two-segment mode: 320-slot segments
+        const int slot = 320 * seg + 32 * idx;
+        a_src[k] = (unsigned)(slot + seg * a.seg_delta) * (unsigned)a.cs_in * 4u;
+        // bit 0 marks the last piece of a window (of a segment): only its first a_tail positions are ever read; the
+        // other lanes re-fetch the last of those instead of positions nobody uses
+        a_dst[k] = (unsigned)slot * 32u + (idx == a.a_per_seg - 1 ? 1u : 0u);
     }
-    const unsigned tail_lim = (unsigned)(a.a_tail - 1) * (unsigned)a.cs_in * 4u;
+    const unsigned tail_lim = ((unsigned)(a.a_tail - 1) * (unsigned)a.cs_in + 4u) * 4u;
     const unsigned b_src0 = 1024u * jb0, b_dst0 = (unsigned)(A_F4 + 64 * jb0) * 16u;
 
     // slot 0 = this wave's pieces k < PER_SLOT, slot 1 = the rest; k is a compile-time index
@@ -590,14 +591,14 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
         const bool more = ntile < ntiles;
         const float4 *base = lds + buf * BUF_F4;
         // lane (r16, q4): row r16 of a 16-position block, tap q4 -> slot offset (q4&1) + (q4>>1)*seg_slot
-        const float4 *ap = base + 32 * w + r16 + (q4 & 1) + (q4 >> 1) * a.seg_slot;   // + 16*mb + half*A_HALF
+        const float4 *ap = base + 2 * (32 * w + r16 + (q4 & 1) + (q4 >> 1) * a.seg_slot);   // + 32*mb + half
         const bf16x8 *bp = reinterpret_cast<const bf16x8 *>(base + A_F4) + q4 * NP + r16;   // + pl*4*NP + 16*nb
 
         float4 ra[2][2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) ra[mb][hf] = ap[16 * mb + hf * A_HALF];
+            for (int hf = 0; hf < 2; ++hf) ra[mb][hf] = ap[32 * mb + hf];
         bf16x8 bq[3][PL];                                      // rotating [slot][plane] weight fragments
 #pragma unroll
         for (int g0 = 0; g0 < 2; ++g0)
@@ -1856,12 +1857,11 @@ static int conv_split_impl(const char *who, int planes, const float *in, int cs_
     a.divP = make_magic((unsigned)g.P); a.divR = make_magic((unsigned)g.R); a.R = g.R;
     MMLF_CHECK_ARG(g.NQpad + g.P + 64 < (1ll << 31), "%s: batch x image too large for 32-bit grid positions", who);
     if (g.P + 257 <= 640) {   // one contiguous window of 257 + P positions
-        a.a_pieces = (g.P + 257 + 63) / 64; a.seg_slot = g.P; a.seg_delta = 0;
-        a.a_tail = g.P + 257 - 64 * (a.a_pieces - 1);
-    } else {                  // two 320-slot segments: rows y and y+1
-        a.a_pieces = 10; a.seg_slot = 320; a.seg_delta = g.P - 320;
-        a.a_tail = 1;         // positions Q0 .. Q0 + 256 of each row
+        a.a_pieces = a.a_per_seg = (g.P + 257 + 31) / 32; a.seg_slot = g.P; a.seg_delta = 0;
+    } else {                  // two 320-slot segments: rows y and y+1, positions Q0 .. Q0 + 256 of each
+        a.a_per_seg = 9; a.a_pieces = 18; a.seg_slot = 320; a.seg_delta = g.P - 320;
     }
+    a.a_tail = (a.seg_delta ? 257 : g.P + 257) - 32 * (a.a_per_seg - 1);
     const long long ntiles = g.NQpad / MMLF_TILE;
     hipStream_t st = (hipStream_t)stream;
     return planes == 3 ? launch_conv_split<3>(np, a, ntiles, st) : launch_conv_split<2>(np, a, ntiles, st);
