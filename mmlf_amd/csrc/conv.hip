@@ -185,34 +185,23 @@ __host__ __device__ __forceinline__ float pow2_scale_for(float amax)
     __builtin_memcpy(&r, &u, 4);
     return r;
 }
-// SCALAR: plain (unpacked) f32 VALU for code that runs BESIDE MFMAs, where a v_pk_*_f32 costs more issue time
-// than the two scalar instructions it replaces (wgrad staging, the pipelined conv: +2 %); at a chunk head with
-// no MFMA in flight the packed form is the faster one (conv4tap_x6s_kernel: scalar there costs 5 %).
+// Two instructions per element: v_fma_mix{lo,hi}_f16 computes fma(x, s, c) in f32 and rounds ONCE to f16, so
+// hi = f16(x * s) and lo = f16(x * s - hi) (the product by a power of two is exact, the difference is formed
+// exactly inside the fma) -- the same bits as multiply / convert / convert back / subtract / convert (five to six
+// instructions per element), which is what these kernels ran before; the split is the main loop's vector work, and
+// vector instructions beside MFMAs are what the loops are short of.  SCALAR is kept as a tag only.
 template <bool SCALAR = false>
 __device__ __forceinline__ void split2_pair_f16(float a, float b, float s, unsigned &h, unsigned &l)
 {
-    if constexpr (SCALAR) {
-        float va, vb, ra, rb;
-        asm("v_mul_f32 %0, %1, %2" : "=v"(va) : "s"(s), "v"(a));
-        asm("v_mul_f32 %0, %1, %2" : "=v"(vb) : "s"(s), "v"(b));
-        const f32x2_t v0 = {va, vb};
-        const f16x2_t hh0 = __builtin_convertvector(v0, f16x2_t);
-        const f32x2_t back0 = __builtin_convertvector(hh0, f32x2_t);
-        asm("v_sub_f32 %0, %1, %2" : "=v"(ra) : "v"(va), "v"(back0[0]));
-        asm("v_sub_f32 %0, %1, %2" : "=v"(rb) : "v"(vb), "v"(back0[1]));
-        const f32x2_t r0 = {ra, rb};
-        const f16x2_t ll0 = __builtin_convertvector(r0, f16x2_t);
-        h = __builtin_bit_cast(unsigned, hh0);
-        l = __builtin_bit_cast(unsigned, ll0);
-    } else {
-        const f32x2_t v = {a * s, b * s};
-        const f16x2_t hh = __builtin_convertvector(v, f16x2_t);
-        const f32x2_t back = __builtin_convertvector(hh, f32x2_t);
-        const f32x2_t r = {v[0] - back[0], v[1] - back[1]};
-        const f16x2_t ll = __builtin_convertvector(r, f16x2_t);
-        h = __builtin_bit_cast(unsigned, hh);
-        l = __builtin_bit_cast(unsigned, ll);
-    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float su = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s)));   // wave-uniform by construction
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "s"(su));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "s"(su));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "s"(su), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "s"(su), "v"(h));
+#else
+    h = l = 0;
+#endif
 }
 // f16-split filter packing: [chunk][plane(2)][tap(4)][NP][8 f16] of w * scale[n], one workgroup per packed
 // column n (= output channel of the launch).  Every column carries its own power-of-two scale (its max |w|
