@@ -621,13 +621,11 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
                 for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bp[pl * 4 * NP + 16 * (g + 2)];
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
+            if (more) {   // both slots of a wave in one go, as early as the buffer is free; the two waves of a SIMD apart
                 if (w < 4) {
-                    if (g == 0) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
-                    if (g == (PL == 2 && G >= 8 ? G / 4 : G / 2)) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
+                    if (g == 0) { X6_DMA_SLOT(ntile, nc, buf ^ 1, 0); X6_DMA_SLOT(ntile, nc, buf ^ 1, 1); }
                 } else {
-                    if (g == (PL == 2 && G >= 8 ? G / 8 : G / 4)) X6_DMA_SLOT(ntile, nc, buf ^ 1, 0);
-                    if (g == (PL == 2 && G >= 8 ? (3 * G) / 8 : G / 2 + G / 4)) X6_DMA_SLOT(ntile, nc, buf ^ 1, 1);
+                    if (g == (PL == 2 && G >= 8 ? G / 8 : G / 4)) { X6_DMA_SLOT(ntile, nc, buf ^ 1, 0); X6_DMA_SLOT(ntile, nc, buf ^ 1, 1); }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
