@@ -1303,23 +1303,28 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     float4 ra[NA], rg[NG];
     // staging items are clamped to the last one instead of predicated: surplus threads load and store that
     // item again (same value), which keeps the loop free of divergent branches
-#define WW_GLOAD(c)                                                                                         \
+#define WW_GLOAD_A(j, c)                                                                                    \
     do {                                                                                                    \
         const long long Qc = (long long)(c) * WG_KQ;                                                        \
-        _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
-            const int idx = min(tid + 512 * j, 66 * FA - 1);                                                \
-            const int row = idx / FA, f = idx - row * FA;                                                   \
-            const int seg = row >= 33, pix = row - 33 * seg;                                                \
-            const int ch = min(ci0 + 4 * f, a.cs_in - 4);                                                   \
-            const float4 v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
-            ra[j] = (ci0 + 4 * f < a.cs_in) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                          \
-        }                                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
-            const int idx = min(tid + 512 * j, WG_KQ * FG - 1);                                             \
-            const int row = idx / FG, f = idx - row * FG;                                                   \
-            const float4 v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + min(4 * f, a.cs_g - 4)); \
-            rg[j] = (4 * f < a.cs_g) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                 \
-        }                                                                                                   \
+        const int idx = min(tid + 512 * (j), 66 * FA - 1);                                                  \
+        const int row = idx / FA, f = idx - row * FA;                                                       \
+        const int seg = row >= 33, pix = row - 33 * seg;                                                    \
+        const int ch = min(ci0 + 4 * f, a.cs_in - 4);                                                       \
+        const float4 v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
+        ra[j] = (ci0 + 4 * f < a.cs_in) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                              \
+    } while (0)
+#define WW_GLOAD_G(j, c)                                                                                    \
+    do {                                                                                                    \
+        const long long Qc = (long long)(c) * WG_KQ;                                                        \
+        const int idx = min(tid + 512 * (j), WG_KQ * FG - 1);                                               \
+        const int row = idx / FG, f = idx - row * FG;                                                       \
+        const float4 v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + min(4 * f, a.cs_g - 4)); \
+        rg[j] = (4 * f < a.cs_g) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+    } while (0)
+#define WW_GLOAD(c)                                                                                         \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NA; ++j) WW_GLOAD_A(j, c);                                    \
+        _Pragma("unroll") for (int j = 0; j < NG; ++j) WW_GLOAD_G(j, c);                                    \
     } while (0)
 #define WW_STORE_A(j, dst)                                                                                  \
     do {                                                                                                    \
@@ -1358,11 +1363,13 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         int buf = 0;
         // One chunk: gradient fragments are read one column block ahead (two register sets); with STAGE the
         // registers holding chunk c+1 are split and stored into the other buffer, one piece per column
-        // block, branch-free so that the stores interleave with the MFMAs.
+        // block, branch-free so that the stores interleave with the MFMAs -- and the register a piece leaves is
+        // loaded with the same piece of chunk c+2 right away: a whole chunk between a global load and its use
+        // (loaded in bulk at the end of the chunk, every load was waited for at the next chunk's first column blocks).
 #define WW_TERM(gf, pa, pb)                                                                                  \
     _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                        \
         acc[mb][nb] = mfma16_pl<PL>(af[mb][pa], gf[pb], acc[mb][nb])
-#define WW_CHUNK(STAGE)                                                                                      \
+#define WW_CHUNK(STAGE, RELOAD)                                                                              \
     do {                                                                                                     \
         const char *cur = smem + buf * BUF_BYTES;                                                            \
         char *nxt = smem + (buf ^ 1) * BUF_BYTES;                                                            \
@@ -1378,8 +1385,13 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
                     gfr[(nb + 1) & 1][pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * (nb + 1), 4 * ROWG);   \
             }                                                                                                \
             if (STAGE) {                                                                                     \
-                if (nb < NA) WW_STORE_A(nb < NA ? nb : 0, nxt);                                              \
-                else if (nb - NA < NG) WW_STORE_G(nb - NA < NG ? nb - NA : 0, nxt);                          \
+                if (nb < NA) {                                                                               \
+                    WW_STORE_A(nb < NA ? nb : 0, nxt);                                                       \
+                    if (RELOAD) WW_GLOAD_A(nb < NA ? nb : 0, c + 2);                                         \
+                } else if (nb - NA < NG) {                                                                   \
+                    WW_STORE_G(nb - NA < NG ? nb - NA : 0, nxt);                                             \
+                    if (RELOAD) WW_GLOAD_G(nb - NA < NG ? nb - NA : 0, c + 2);                               \
+                }                                                                                            \
             }                                                                                                \
             _Pragma("unroll") for (int term = 0; term < (PL == 3 ? 6 : 3); ++term)                           \
                 WW_TERM(gfr[nb & 1], term_a<PL>(term), term_b<PL>(term));                                    \
@@ -1388,16 +1400,22 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         static_assert(NA + NG <= NBH, "one staging piece per column block");
         for (int c = c_begin; c + 1 < c_end; ++c) {
             wgrad_chunk_scale<PL>(a, c + 1, st_sa, st_sg);
-            WW_CHUNK(true);
-            if (c + 2 < c_end) WW_GLOAD(c + 2);
+            const bool reload = c + 2 < c_end;
+            WW_CHUNK(true, reload);
             __syncthreads();
             buf ^= 1;
         }
-        WW_CHUNK(false);                     // last chunk: nothing left to stage
+        {
+            const int c = c_end - 1;
+            (void)c;
+            WW_CHUNK(false, false);          // last chunk: nothing left to stage
+        }
 #undef WW_CHUNK
 #undef WW_TERM
     }
 #undef WW_GLOAD
+#undef WW_GLOAD_A
+#undef WW_GLOAD_G
 #undef WW_STORE_A
 #undef WW_STORE_G
     constexpr int NP = 16 * NB;
