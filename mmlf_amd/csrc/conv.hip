@@ -1361,7 +1361,7 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         if (c_begin + 1 < c_end) WW_GLOAD(c_begin + 1);
         __syncthreads();
         int buf = 0;
-        // One chunk: gradient fragments are read one column block ahead (two register sets); with STAGE the
+        // One chunk: gradient fragments are read two column blocks ahead (three register sets); with STAGE the
         // registers holding chunk c+1 are split and stored into the other buffer, one piece per column
         // block, branch-free so that the stores interleave with the MFMAs -- and the register a piece leaves is
         // loaded with the same piece of chunk c+2 right away: a whole chunk between a global load and its use
@@ -1373,16 +1373,17 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     do {                                                                                                     \
         const char *cur = smem + buf * BUF_BYTES;                                                            \
         char *nxt = smem + (buf ^ 1) * BUF_BYTES;                                                            \
-        bf16x8 af[MB][PL], gfr[2][PL];                                                                         \
-        _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                                     \
-            gfr[0][pl] = tr_frag(cur + g_off + pl * G_PLANE, 4 * ROWG);                                      \
+        bf16x8 af[MB][PL], gfr[3][PL];                                                                         \
+        _Pragma("unroll") for (int g0 = 0; g0 < 2; ++g0)                                                     \
+            _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                                 \
+                gfr[g0][pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * g0, 4 * ROWG);                       \
         _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                    \
             _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                                 \
                 af[mb][pl] = tr_frag(cur + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);                        \
         _Pragma("unroll") for (int nb = 0; nb < NBH; ++nb) {                                                 \
-            if (nb + 1 < NBH) {                                                                              \
+            if (nb + 2 < NBH) {                                                                              \
                 _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                             \
-                    gfr[(nb + 1) & 1][pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * (nb + 1), 4 * ROWG);   \
+                    gfr[(nb + 2) % 3][pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * (nb + 2), 4 * ROWG);   \
             }                                                                                                \
             if (STAGE) {                                                                                     \
                 if (nb < NA) {                                                                               \
@@ -1394,7 +1395,7 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
                 }                                                                                            \
             }                                                                                                \
             _Pragma("unroll") for (int term = 0; term < (PL == 3 ? 6 : 3); ++term)                           \
-                WW_TERM(gfr[nb & 1], term_a<PL>(term), term_b<PL>(term));                                    \
+                WW_TERM(gfr[nb % 3], term_a<PL>(term), term_b<PL>(term));                                    \
         }                                                                                                    \
     } while (0)
         static_assert(NA + NG <= NBH, "one staging piece per column block");
