@@ -1446,19 +1446,28 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__res
     const int ci = r % (Cin + 1);
     const int t = r / (Cin + 1);
     if (ci == Cin && (t != 0 || gb == nullptr)) return;
-    // fixed summation order (splits ascending, four interleaved lanes): deterministic, and four loads in
-    // flight per thread instead of one
+    // fixed summation order (splits ascending, sixteen interleaved lanes): deterministic, and sixteen loads in flight
+    // per thread -- the loop is bound by load latency (128 splits x 1.3 MB apart), not by bytes
     const float *pp = part + ((size_t)t * CIP + ci) * NP + co;
     const size_t stride = (size_t)4 * CIP * NP;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    constexpr int U = 16;
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.0;
     int sp = 0;
-    for (; sp + 4 <= nsplit; sp += 4) {
-        const float a0 = pp[(size_t)sp * stride], a1 = pp[(size_t)(sp + 1) * stride];
-        const float a2 = pp[(size_t)(sp + 2) * stride], a3 = pp[(size_t)(sp + 3) * stride];
-        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    for (; sp + U <= nsplit; sp += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = pp[(size_t)(sp + u) * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += v[u];
     }
-    for (; sp < nsplit; ++sp) s0 += pp[(size_t)sp * stride];
-    const double s = (s0 + s1) + (s2 + s3);
+    for (; sp < nsplit; ++sp) acc[0] += pp[(size_t)sp * stride];
+#pragma unroll
+    for (int h = U / 2; h > 0; h >>= 1)
+#pragma unroll
+        for (int u = 0; u < h; ++u) acc[u] += acc[u + h];
+    const double s = acc[0];
     if (ci == Cin) {
         gb[co] = accumulate ? gb[co] + (float)s : (float)s;
     } else {
