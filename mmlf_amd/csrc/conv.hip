@@ -188,8 +188,8 @@ __host__ __device__ __forceinline__ float pow2_scale_for(float amax)
 // Two instructions per element: v_fma_mix{lo,hi}_f16 computes fma(x, s, c) in f32 and rounds ONCE to f16, so
 // hi = f16(x * s) and lo = f16(x * s - hi) (the product by a power of two is exact, the difference is formed
 // exactly inside the fma) -- the same bits as multiply / convert / convert back / subtract / convert (five to six
-// instructions per element), which is what these kernels ran before; the split is the main loop's vector work, and
-// vector instructions beside MFMAs are what the loops are short of.  SCALAR is kept as a tag only.
+// instructions per element), which is what these kernels ran before (same time, measured: the loops are limited by the
+// board's power, not by vector issue slots -- but fewer instructions are fewer instructions).  SCALAR is a tag only.
 template <bool SCALAR = false>
 __device__ __forceinline__ void split2_pair_f16(float a, float b, float s, unsigned &h, unsigned &l)
 {
