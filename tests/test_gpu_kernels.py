@@ -70,10 +70,13 @@ def test_conv_forward_and_border(oracle, cin, cout, pad, mode, monkeypatch):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'f16x3'])
-@pytest.mark.parametrize('B,H,W', [(1, 3, 400), (1, 1, 1), (2, 2, 700), (5, 96, 96)])
+@pytest.mark.parametrize('B,H,W', [(1, 3, 400), (1, 1, 1), (2, 2, 700), (5, 96, 96), (3, 5, 29), (3, 5, 30), (2, 4, 61),
+                                   (1, 2, 381), (1, 2, 382)])
 def test_conv_wide_and_degenerate_frames(oracle, mode, B, H, W, monkeypatch):
     """Pitch > 383 switches the split kernel to its two-segment activation window; 1x1 images and a
-    batch whose position count is not a tile multiple exercise the ragged ends."""
+    batch whose position count is not a tile multiple exercise the ragged ends.  Widths 29 / 61 (30) make the
+    activation window a whole number of 32-position DMA pieces (one position more), 381 / 382 are the widest
+    single-window pitches: the ends of the last-piece clamp."""
     from mmlf_amd import engine
     monkeypatch.setattr(engine, 'CONV_MODE', mode)
     dev = _dev()
