@@ -108,6 +108,11 @@ class Ensamble(nn.Module):
         b, views, c, hh, ww = h.shape
         S = len(disps)
         dev = h.device
+        for name, t in (('v_views', v), ('i_views', i), ('d_views', d)):
+            if t.device != dev or t.dtype != torch.float32 or tuple(t.shape) != tuple(h.shape):
+                # raw pointers go to the shift kernel: a tensor of another device would fault inside it
+                raise ValueError(f'Ensamble: {name} must be a float32 tensor of shape {tuple(h.shape)} on {dev}, '
+                                 f'got {t.dtype} {tuple(t.shape)} on {t.device}')
         model = self.model
         inner = model.module if hasattr(model, 'module') else model
         tab_s, tab_w = shift_table(disps, views)
