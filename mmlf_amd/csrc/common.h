@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #define MMLF_TILE 256  // positions per conv tile (== MMLF_TILE_POSITIONS)
+#define MMLF_TILE_MAX 512  // ... of the sixteen-wave variant of the narrow layers: grids are padded to this
 
 extern thread_local char g_mmlf_err[512];
 
@@ -60,7 +61,7 @@ static inline Grid make_grid(int B, int H, int W)
     g.B = B; g.H = H; g.W = W;
     g.P = W + 2; g.R = H + 2; g.G = g.P * g.R;
     g.NQ = (long long)B * g.G;
-    g.NQpad = (g.NQ + MMLF_TILE - 1) / MMLF_TILE * MMLF_TILE;
+    g.NQpad = (g.NQ + MMLF_TILE_MAX - 1) / MMLF_TILE_MAX * MMLF_TILE_MAX;
     return g;
 }
 

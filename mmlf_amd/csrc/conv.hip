@@ -9,6 +9,7 @@
 // All three are 4-tap correlations over the flat grid position q with tap offsets
 // {0, 1, P, P+1} (include/mmlf_hip.h).  v_mfma_f32_32x32x2_f32 is an exact f32 fma chain, so the
 // exact-f32 path is float32-exact up to summation order.
+#include <cstdlib>
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/mmlf_hip.h"
@@ -53,6 +54,7 @@ struct ConvArgs {
     int cs_in, nchunk, cs_out, n_store, n_true, out_shift, vh, vw, P, G, relu, cs_ref;
     int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6s_kernel): 32-position pieces,
     int a_per_seg, a_tail;               // ... pieces per segment, positions the last piece of a segment has to fetch
+    int nw;                              // waves per workgroup the launch uses (8, or 16: 512-position tiles)
     const float *in_amax;                // f16 split: amax array of `in` (common.h): per-wave power-of-two operand scales
     const float *w_unscale;              // f16 split: 1 / (power-of-two scale of packed column n), [NP]
     float *out_amax;                     // optional: amax array of `out` (tensor and grid-row maxima, atomic max)
@@ -452,10 +454,16 @@ __device__ __forceinline__ ConvArgs late_args()
 // columns instead of 96), 6, 7, 8 or 18.
 // PL = operand planes: 3 = bf16 3-way split, six passes ("bf16x6"); 2 = f16 2-way split of the scaled
 // operands, three passes ("f16x3").
-template <int G, int PL, int EPI = EPI_GENERIC>
-__global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
+// NW = waves per workgroup = 32-position row groups per tile: 8 (256-position tiles) or, for the narrow layers on small
+// pitches, 16 (512 positions, ONE workgroup per CU instead of two: the 99-position halo is 19 % of the window instead of
+// 39 %, the weights are fetched once per 512 positions, and more activation bytes are in flight per CU -- these launches
+// are bound by memory concurrency, not by the matrix cores).  Layouts (masks, statistics, scales) are indexed by the
+// global 32-position group, so the two variants produce the same bytes.
+template <int G, int PL, int EPI = EPI_GENERIC, int NW = 8>
+__global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
 {
     constexpr int NP = G * 16;
+    constexpr int TILE = 32 * NW;
     // A: [640 slots][channel half(2)] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
     // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
     // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     constexpr int B_F4 = 4 * PL * NP;
     constexpr int BUF_F4 = A_F4 + B_F4;
     constexpr int N_B = B_F4 / 64;
-    constexpr int PER_WAVE = (20 + N_B + 7) / 8;      // upper bound (two-segment mode: 20 A pieces)
+    constexpr int PER_WAVE = (20 + N_B + NW - 1) / NW;   // upper bound (20 A pieces: two-segment mode, 512-position tiles)
     constexpr int PER_SLOT = (PER_WAVE + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *lds = reinterpret_cast<float4 *>(smem);
@@ -491,19 +499,19 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
     const char *in0 = reinterpret_cast<const char *>(a.in);
     const char *wp_base = reinterpret_cast<const char *>(a.wp);
-    const size_t tile_bytes = (size_t)MMLF_TILE * a.cs_in * 4;
+    const size_t tile_bytes = (size_t)TILE * a.cs_in * 4;
     // Piece ownership, fixed for the launch: of the chunk's pieces j = 0 .. a_pieces + N_B - 1 (activation
     // pieces first) wave w issues j = w, w+8, ...: nA activation pieces, then nB weight pieces that are
     // 8 KiB apart in both the packed filter and LDS.  The first half of them goes out in slot 0.
     const int n_a = a.a_pieces;
-    const int nA = (n_a - w + 7) >> 3;
-    const int jb0 = w + 8 * nA - n_a;
-    const int nB = (N_B - jb0 + 7) >> 3;
+    const int nA = (n_a - w + NW - 1) / NW;
+    const int jb0 = w + NW * nA - n_a;
+    const int nB = (N_B - jb0 + NW - 1) / NW;
     int n_mine = nA + nB;                                   // re-made opaque every chunk (see below)
     unsigned a_src[3], a_dst[3];                            // activation pieces: byte offset in the tile, LDS byte
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int j = w + 8 * k;
+        const int j = w + NW * k;
         const int seg = j >= a.a_per_seg, idx = j - seg * a.a_per_seg;   // two-segment mode: 320-slot segments
         const int slot = 320 * seg + 32 * idx;
         a_src[k] = (unsigned)(slot + seg * a.seg_delta) * (unsigned)a.cs_in * 4u;
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
                 vo_ = min(voff_a, (d_ & 1u) ? tail_lim : 0xffffffffu);                                   \
                 d_ &= ~1u;                                                                               \
             } else {                                                                                     \
-                const unsigned kb_ = 8192u * (unsigned)((k) - nA);                                       \
+                const unsigned kb_ = (1024u * NW) * (unsigned)((k) - nA);                                \
                 sb_ = wp_base + (size_t)(c) * (B_F4 * 16) + b_src0 + kb_;                                \
                 vo_ = voff_b;                                                                            \
                 d_ = b_dst0 + kb_;                                                                       \
@@ -557,13 +565,13 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
     if (tile >= ntiles) return;
     // optional BatchNorm statistics of the output: per-wave double sums behind the two pipeline buffers
-    double *stats_all = reinterpret_cast<double *>(lds + 2 * BUF_F4);        // [8 waves][NP][2]
+    double *stats_all = reinterpret_cast<double *>(lds + 2 * BUF_F4);        // [NW waves][NP][2]
     if (late_args().bn_partial)
-        for (int k = tid; k < 8 * NP * 2; k += 512) stats_all[k] = 0.0;      // ordered by the barrier below
+        for (int k = tid; k < NW * NP * 2; k += 64 * NW) stats_all[k] = 0.0;  // ordered by the barrier below
     // f16 split: operand scales (powers of two) and what undoes them in the epilogue
     float scale_a = 1.f, unscale_a = 1.f, run_max = 0.f;
     if constexpr (PL == 2) {
-        scale_a = wave_operand_scale(wave_operand_amax_gather(late_args(), (long long)tile * MMLF_TILE, w, lane));
+        scale_a = wave_operand_scale(wave_operand_amax_gather(late_args(), (long long)tile * TILE, w, lane));
         unscale_a = 1.f / scale_a;
     }
     X6_DMA_SLOT(ntile, nc, 0, 0);
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more) {   // both slots of a wave in one go, as early as the buffer is free; the two waves of a SIMD apart
-                if (w < 4) {
+                if (w < NW / 2) {
                     if (g == 0) { X6_DMA_SLOT(ntile, nc, buf ^ 1, 0); X6_DMA_SLOT(ntile, nc, buf ^ 1, 1); }
                 } else {
                     if (g == (PL == 2 && G >= 8 ? G / 8 : G / 4)) { X6_DMA_SLOT(ntile, nc, buf ^ 1, 0); X6_DMA_SLOT(ntile, nc, buf ^ 1, 1); }
@@ -663,8 +671,8 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
             float next_amax = 0.f;          // the next tile's row maxima: loads in flight during the epilogue
             if constexpr (PL == 2)
                 if (tile + (int)gridDim.x < ntiles)
-                    next_amax = wave_operand_amax_gather(e, (long long)(tile + gridDim.x) * MMLF_TILE, w, lane);
-            conv_epilogue16<G, EPI>(e, acc, (long long)tile * MMLF_TILE, w, r16, q4, unscale_a, run_max,
+                    next_amax = wave_operand_amax_gather(e, (long long)(tile + gridDim.x) * TILE, w, lane);
+            conv_epilogue16<G, EPI>(e, acc, (long long)tile * TILE, w, r16, q4, unscale_a, run_max,
                                e.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -687,11 +695,11 @@ __global__ __launch_bounds__(512, (G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(Con
     const ConvArgs e = late_args();
     if (e.out_amax) mmlf_amax_update(run_max, e.out_amax);      // at most one atomic per wave per launch
     if (e.bn_partial) {                                         // the loop's last barrier ordered the wave sums
-        for (int k = tid; k < 2 * e.n_true; k += 512) {
+        for (int k = tid; k < 2 * e.n_true; k += 64 * NW) {
             const int ch = k % e.n_true, which = k / e.n_true;
             double t = 0.0;
 #pragma unroll
-            for (int ww = 0; ww < 8; ++ww) t += stats_all[((size_t)ww * NP + ch) * 2 + which];
+            for (int ww = 0; ww < NW; ++ww) t += stats_all[((size_t)ww * NP + ch) * 2 + which];
             e.bn_partial[((size_t)blockIdx.x * 2 + which) * e.n_true + ch] = t;
         }
     }
@@ -1781,11 +1789,18 @@ static int device_cus()
     return cus[dev];
 }
 
-// persistent launches: one workgroup per CU (two for the narrow variants), each walks tiles b, b+grid, ...
-static long long conv_split_blocks(int G, long long ntiles)
+// persistent launches: one workgroup per CU (two for the narrow eight-wave variants), each walks tiles b, b+grid, ...
+static long long conv_split_blocks(int G, long long ntiles, int nw = 8)
 {
-    const long long grid = (G <= 6 ? 2ll : 1ll) * device_cus();
+    const long long grid = (G <= 6 && nw == 8 ? 2ll : 1ll) * device_cus();
     return grid > ntiles ? ntiles : grid;
+}
+// The sixteen-wave variant (512-position tiles) serves the 80-column f16 kernels on pitches whose 513 + P position
+// window fits the 640-slot activation buffer (MMLF_CONV_NW16=0 turns it off).
+static bool conv_sixteen_waves(int planes, int np, const Grid &g)
+{
+    static const int on = [] { const char *e = getenv("MMLF_CONV_NW16"); return e ? atoi(e) : 1; }();
+    return on && planes == 2 && np == 80 && g.P + 513 <= 640;
 }
 
 template <int G, int PL, int EPI>
@@ -1797,6 +1812,20 @@ static int launch_conv_x6s_epi(const ConvArgs &a, long long ntiles, hipStream_t 
     if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_pipe + (PL == 2 ? lds_stats : 0)));
+    }
+    if constexpr (PL == 2 && G == 5) {
+        if (a.nw == 16) {
+            constexpr size_t lds_stats16 = 16 * (G * 16) * 2 * sizeof(double);
+            static PerDeviceOnce attr_once16;
+            if (attr_once16.first()) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI, 16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_pipe + lds_stats16));
+            }
+            const size_t lds16 = lds_pipe + (a.bn_partial ? lds_stats16 : 0);
+            const long long grid16 = conv_split_blocks(G, ntiles, 16);
+            hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI, 16>), dim3((unsigned)grid16), dim3(1024), lds16, st, a, (int)ntiles);
+            return mmlf_launch_status("mmlf_conv2x2_h2(16 waves)");
+        }
     }
     const size_t lds = lds_pipe + (a.bn_partial ? lds_stats : 0);
     const long long grid = conv_split_blocks(G, ntiles);
@@ -1871,13 +1900,15 @@ static int conv_split_impl(const char *who, int planes, const float *in, int cs_
                               : nullptr;
     a.divP = make_magic((unsigned)g.P); a.divR = make_magic((unsigned)g.R); a.R = g.R;
     MMLF_CHECK_ARG(g.NQpad + g.P + 64 < (1ll << 31), "%s: batch x image too large for 32-bit grid positions", who);
-    if (g.P + 257 <= 640) {   // one contiguous window of 257 + P positions
-        a.a_pieces = a.a_per_seg = (g.P + 257 + 31) / 32; a.seg_slot = g.P; a.seg_delta = 0;
+    a.nw = conv_sixteen_waves(planes, np, g) ? 16 : 8;
+    const int tile = 32 * a.nw;
+    if (g.P + tile + 1 <= 640) {   // one contiguous window of tile + 1 + P positions
+        a.a_pieces = a.a_per_seg = (g.P + tile + 1 + 31) / 32; a.seg_slot = g.P; a.seg_delta = 0;
     } else {                  // two 320-slot segments: rows y and y+1, positions Q0 .. Q0 + 256 of each
         a.a_per_seg = 9; a.a_pieces = 18; a.seg_slot = 320; a.seg_delta = g.P - 320;
     }
-    a.a_tail = (a.seg_delta ? 257 : g.P + 257) - 32 * (a.a_per_seg - 1);
-    const long long ntiles = g.NQpad / MMLF_TILE;
+    a.a_tail = (a.seg_delta ? 257 : g.P + tile + 1) - 32 * (a.a_per_seg - 1);
+    const long long ntiles = g.NQpad / tile;
     hipStream_t st = (hipStream_t)stream;
     return planes == 3 ? launch_conv_split<3>(np, a, ntiles, st) : launch_conv_split<2>(np, a, ntiles, st);
 }
@@ -1936,7 +1967,8 @@ extern "C" int mmlf_conv2x2_blocks(int N, int B, int H, int W)
     const int np = x6_np(N);
     if (np < 0 || B <= 0 || H <= 0 || W <= 0) return -1;
     const Grid g = make_grid(B, H, W);
-    return (int)conv_split_blocks(np / 16, g.NQpad / MMLF_TILE);
+    const int nw = conv_sixteen_waves(2, np, g) ? 16 : 8;
+    return (int)conv_split_blocks(np / 16, g.NQpad / (32 * nw), nw);
 }
 
 // ---------------------------------------------------------------------------------------------
