@@ -75,6 +75,9 @@ struct ConvArgs {
 //  * addressing: buffer instructions on a wave-uniform tile descriptor + 32-bit per-lane byte offsets
 //    (the column-block offset folds into the instruction's immediate);
 //  * bias and (data-gradient) ReLU-reference values are loaded in batches ahead of their use.
+#ifndef MMLF_RING16
+#define MMLF_RING16 3   // pipeline depth of the sixteen-wave conv variant (LDS: 30 KB per buffer + 20 KB; 4 measures the same)
+#endif
 #define MMLF_BUF_FLAGS 0x00020000   // raw dword buffer (DATA_FORMAT_32), no swizzle
 __device__ __forceinline__ unsigned wave_row_mask(const ConvArgs &a, long long Q0, int w, int lane)
 {
@@ -464,6 +467,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
 {
     constexpr int NP = G * 16;
     constexpr int TILE = 32 * NW;
+    // pipeline buffers: two; the sixteen-wave variant has the LDS for a ring of MMLF_RING16, with the DMA of chunk
+    // c + D - 1 issued during chunk c and a counted wait that leaves the newest D - 2 chunks' pieces in flight
+    constexpr int D = NW == 16 ? MMLF_RING16 : 2;
     // A: [640 slots][channel half(2)] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
     // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
     // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
     if (tile >= ntiles) return;
     // optional BatchNorm statistics of the output: per-wave double sums behind the two pipeline buffers
-    double *stats_all = reinterpret_cast<double *>(lds + 2 * BUF_F4);        // [NW waves][NP][2]
+    double *stats_all = reinterpret_cast<double *>(lds + D * BUF_F4);        // [NW waves][NP][2]
     if (late_args().bn_partial)
         for (int k = tid; k < NW * NP * 2; k += 64 * NW) stats_all[k] = 0.0;  // ordered by the barrier below
     // f16 split: operand scales (powers of two) and what undoes them in the epilogue
@@ -574,9 +580,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         scale_a = wave_operand_scale(wave_operand_amax_gather(late_args(), (long long)tile * TILE, w, lane));
         unscale_a = 1.f / scale_a;
     }
-    X6_DMA_SLOT(ntile, nc, 0, 0);
-    X6_DMA_SLOT(ntile, nc, 0, 1);
-    if (++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+        if (ntile < ntiles) {
+            X6_DMA_SLOT(ntile, nc, d, 0);
+            X6_DMA_SLOT(ntile, nc, d, 1);
+        }
+        if (++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
+    }
     X6_DMA_WAIT();
     __syncthreads();
     int buf = 0;
@@ -586,6 +597,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         // of the persistent loop into (spilled) SGPRs; they are recomputed on the scalar unit instead
         asm volatile("" : "+s"(n_mine));
         const bool more = ntile < ntiles;
+        const int fb = buf == 0 ? D - 1 : buf - 1;             // the buffer multiplied last: free for chunk c + D - 1
         const float4 *base = lds + buf * BUF_F4;
         // lane (r16, q4): row r16 of a 16-position block, tap q4 -> slot offset (q4&1) + (q4>>1)*seg_slot
         const float4 *ap = base + 2 * (32 * w + r16 + (q4 & 1) + (q4 >> 1) * a.seg_slot);   // + 32*mb + half
@@ -631,9 +643,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             __builtin_amdgcn_sched_barrier(0);
             if (more) {   // both slots of a wave in one go, as early as the buffer is free; the two waves of a SIMD apart
                 if (w < NW / 2) {
-                    if (g == 0) { X6_DMA_SLOT(ntile, nc, buf ^ 1, 0); X6_DMA_SLOT(ntile, nc, buf ^ 1, 1); }
+                    if (g == 0) { X6_DMA_SLOT(ntile, nc, fb, 0); X6_DMA_SLOT(ntile, nc, fb, 1); }
                 } else {
-                    if (g == (PL == 2 && G >= 8 ? G / 8 : G / 4)) { X6_DMA_SLOT(ntile, nc, buf ^ 1, 0); X6_DMA_SLOT(ntile, nc, buf ^ 1, 1); }
+                    if (g == (PL == 2 && G >= 8 ? G / 8 : G / 4)) { X6_DMA_SLOT(ntile, nc, fb, 0); X6_DMA_SLOT(ntile, nc, fb, 1); }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -665,7 +677,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
         // the next chunk's DMA pieces must have landed before the barrier; at a tile end wait for them
         // BEFORE the epilogue, so that its stores (same counter) stay in flight across the barrier
-        X6_DMA_WAIT();
+        if (D > 2 && more) {      // in-order counter: everything but this wave's newest (D - 2) x n_mine pieces has landed
+            static_assert(PER_WAVE <= 3 || D == 2, "counted waits are written for up to three pieces per wave");
+            if (n_mine == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (D - 2)) : "memory");
+            else if (n_mine == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 2)) : "memory");
+            else if (n_mine == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (D - 2)) : "memory");
+            else X6_DMA_WAIT();
+        } else {
+            X6_DMA_WAIT();
+        }
         if (++c == a.nchunk) {
             const ConvArgs e = late_args(); // epilogue-only arguments: loaded here, dead again at the barrier
             float next_amax = 0.f;          // the next tile's row maxima: loads in flight during the epilogue
@@ -690,7 +710,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             }
         }
         __syncthreads();
-        buf ^= 1;
+        buf = buf + 1 == D ? 0 : buf + 1;
     }
     const ConvArgs e = late_args();
     if (e.out_amax) mmlf_amax_update(run_max, e.out_amax);      // at most one atomic per wave per launch
@@ -1819,9 +1839,10 @@ static int launch_conv_x6s_epi(const ConvArgs &a, long long ntiles, hipStream_t 
             static PerDeviceOnce attr_once16;
             if (attr_once16.first()) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI, 16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_pipe + lds_stats16));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MMLF_RING16 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4) + lds_stats16));
             }
-            const size_t lds16 = lds_pipe + (a.bn_partial ? lds_stats16 : 0);
+            constexpr size_t lds_pipe16 = MMLF_RING16 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
+            const size_t lds16 = lds_pipe16 + (a.bn_partial ? lds_stats16 : 0);
             const long long grid16 = conv_split_blocks(G, ntiles, 16);
             hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI, 16>), dim3((unsigned)grid16), dim3(1024), lds16, st, a, (int)ntiles);
             return mmlf_launch_status("mmlf_conv2x2_h2(16 waves)");
