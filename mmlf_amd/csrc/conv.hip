@@ -331,12 +331,24 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
     unsigned mw[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) mw[k] = use_bits ? a.relu_mask_in[mbase + 64 * k] : 0u;
+    // bias and weight-unscale of all of this lane's columns up front: a load between the stores makes the compiler
+    // wait for the wave's vector-memory counter to reach zero there, i.e. for every store issued so far (and every DMA
+    // piece in flight) -- once per column block
+    float bv[G], uwv[G];
+#pragma unroll
+    for (int nb = 0; nb < G; ++nb) {
+        const int ch = 16 * nb + r16;
+        bv[nb] = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
+        uwv[nb] = (a.w_unscale && ch < 16 * G) ? a.w_unscale[ch] : 1.f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < G; ++nb) asm volatile("" : "+v"(bv[nb]), "+v"(uwv[nb]));   // loaded HERE, not sunk to their uses
 #pragma unroll
     for (int nb = 0; nb < G; ++nb) {
         const int ch = 16 * nb + r16;
         if (ch >= a.n_store) continue;
-        const float bvn = (a.bias && ch < a.n_true) ? a.bias[ch] : 0.f;
-        const float uw = a.w_unscale ? a.w_unscale[ch] : 1.f;
+        const float bvn = bv[nb];
+        const float uw = uwv[nb];
         unsigned keep = m;
         float s1 = 0.f, s2 = 0.f;
         if (use_bits) {
