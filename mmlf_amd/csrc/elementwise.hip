@@ -25,46 +25,54 @@ extern "C" int64_t mmlf_grid_alloc_positions(int B, int H, int W)
 // group) so that a thread keeps a fixed channel group; double accumulators.
 // ---------------------------------------------------------------------------------------------
 template <int V> struct VecIO;
+// Four floats at an address that is 16-byte aligned -- or only 8-byte aligned: the 70-channel stream slices of the
+// 280-channel concat buffer start at 280-byte multiples, and a float4 group of such a slice is two float2 accesses
+// (uniform over the launch: the same branch for every lane).  Half the threads and instructions of a float2 kernel.
 template <> struct VecIO<4> {
+    static __device__ __forceinline__ bool aligned(const float *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
     static __device__ __forceinline__ void load(const float *p, float *o)
     {
-        const float4 v = *reinterpret_cast<const float4 *>(p);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        if (aligned(p)) {
+            const float4 v = *reinterpret_cast<const float4 *>(p);
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        } else {
+            const float2 a = *reinterpret_cast<const float2 *>(p), b = *reinterpret_cast<const float2 *>(p + 2);
+            o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+        }
     }
     static __device__ __forceinline__ void store(float *p, const float *o)
     {
-        *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+        if (aligned(p)) {
+            *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            *reinterpret_cast<float2 *>(p) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2 *>(p + 2) = make_float2(o[2], o[3]);
+        }
     }
     // streamed once: keep it out of the way of data that is re-read
     static __device__ __forceinline__ void load_nt(const float *p, float *o)
     {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
-        o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        if (aligned(p)) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        } else {
+            load(p, o);
+        }
     }
     static __device__ __forceinline__ void store_nt(float *p, const float *o)
     {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4 v = {o[0], o[1], o[2], o[3]};
-        __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+        if (aligned(p)) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 v = {o[0], o[1], o[2], o[3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+        } else {
+            store(p, o);
+        }
     }
-};
-template <> struct VecIO<2> {
-    static __device__ __forceinline__ void load(const float *p, float *o)
-    {
-        const float2 v = *reinterpret_cast<const float2 *>(p);
-        o[0] = v.x; o[1] = v.y;
-    }
-    static __device__ __forceinline__ void store(float *p, const float *o)
-    {
-        *reinterpret_cast<float2 *>(p) = make_float2(o[0], o[1]);
-    }
-    static __device__ __forceinline__ void load_nt(const float *p, float *o) { load(p, o); }
-    static __device__ __forceinline__ void store_nt(float *p, const float *o) { store(p, o); }
 };
 
-// V = channels per thread access (4 when every slice start is 16-byte aligned, else 2: the
-// 70-channel stream slices of the 280-channel concat buffer start at 280-byte multiples).
+// V = channels per thread access (4; slices that are only 8-byte aligned go through VecIO<4>'s two-float2 form).
 template <bool BWD, int V>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ z, int cs_z,
                                                         const float *__restrict__ gy, int cs_gy, int c_off,
@@ -1061,12 +1069,8 @@ extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *
     MMLF_CHECK_ARG(cs_z % 4 == 0 && cs_y % 2 == 0 && c_off % 2 == 0 && C <= cs_z && C_store >= C &&
                        c_off + C_store <= cs_y,
                    "mmlf_bn_apply_relu: C=%d cs_z=%d cs_y=%d c_off=%d C_store=%d", C, cs_z, cs_y, c_off, C_store);
-    if (cs_y % 4 == 0 && c_off % 4 == 0)
-        hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
-                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out);
-    else
-        hipLaunchKernelGGL((bn_rows_kernel<0, 2>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
-                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out);
+    hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
+                       nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out);
     return mmlf_launch_status("mmlf_bn_apply_relu");
 }
 
@@ -1082,12 +1086,8 @@ extern "C" int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const f
                    "mmlf_bn_bwd_reduce: layout");
     MMLF_CHECK_ARG(nblocks > 0 && nblocks <= 4096, "mmlf_bn_bwd_reduce: nblocks=%d", nblocks);
     hipStream_t st = (hipStream_t)stream;
-    if (cs_gy % 4 == 0 && c_off % 4 == 0)
-        hipLaunchKernelGGL((bn_reduce_kernel<true, 4>), dim3(nblocks), dim3(256), 0, st, z, cs_z, gy, cs_gy, c_off,
-                           scale, shift, save_mean, save_invstd, C, partial, B, H, W);
-    else
-        hipLaunchKernelGGL((bn_reduce_kernel<true, 2>), dim3(nblocks), dim3(256), 0, st, z, cs_z, gy, cs_gy, c_off,
-                           scale, shift, save_mean, save_invstd, C, partial, B, H, W);
+    hipLaunchKernelGGL((bn_reduce_kernel<true, 4>), dim3(nblocks), dim3(256), 0, st, z, cs_z, gy, cs_gy, c_off,
+                       scale, shift, save_mean, save_invstd, C, partial, B, H, W);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, nblocks, C,
                        (double)B * H * W, gamma, save_invstd, dgamma, dbeta, accumulate, coef);
     return mmlf_launch_status("mmlf_bn_bwd_reduce");
@@ -1100,12 +1100,8 @@ extern "C" int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const fl
     MMLF_CHECK_ARG(gy && z && scale && shift && save_mean && coef && dz, "mmlf_bn_bwd_apply: null pointer");
     MMLF_CHECK_ARG(cs_gy % 2 == 0 && c_off % 2 == 0 && cs_z % 4 == 0 && cs_dz % 4 == 0 && C <= cs_dz,
                    "mmlf_bn_bwd_apply: layout");
-    if (cs_gy % 4 == 0 && c_off % 4 == 0)
-        hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
-                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out);
-    else
-        hipLaunchKernelGGL((bn_rows_kernel<1, 2>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
-                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out);
+    hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
+                       cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out);
     return mmlf_launch_status("mmlf_bn_bwd_apply");
 }
 
