@@ -302,29 +302,39 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
 }
 
 // NCHW <-> grid
+#define PACK_XT 128   // positions per transpose tile of pack_nchw_kernel
 __global__ __launch_bounds__(256) void pack_nchw_kernel(const float *__restrict__ src, int C,
                                                         float *__restrict__ grid, int cs, int H, int W,
                                                         float *__restrict__ amax)
 {
+    // a transpose through LDS: the NCHW planes are read with x across the lanes, the grid row is written with the channel
+    // groups across the lanes (whole 16*c4n-byte position rows per instruction instead of one 16-byte piece per line)
+    extern __shared__ float tile[];            // [cs][PACK_XT | 1]: channel-major, odd pitch (conflict-free both ways)
     float mx = 0.f;
     const int P = W + 2, R = H + 2;
     const int row = blockIdx.x;
     const int b = row / R, y = row - b * R;
     const size_t base = (size_t)row * P;
     const int c4n = cs / 4;
+    constexpr int pitch = PACK_XT | 1;
     const bool row_in = (y >= 1 && y <= H);
-    const int total = P * c4n;
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int cg = e / P, x = e - cg * P;  // x fastest: coalesced NCHW reads
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row_in && x >= 1 && x <= W) {
-            for (int k = 0; k < 4; ++k) {
-                const int c = 4 * cg + k;
-                if (c < C) o[k] = src[(((size_t)b * C + c) * H + (y - 1)) * W + (x - 1)];
-            }
+    for (int x0 = 0; x0 < P; x0 += PACK_XT) {                  // the row in pieces of PACK_XT positions
+        const int nx = min(PACK_XT, P - x0);
+        for (int e = threadIdx.x; e < cs * nx; e += blockDim.x) {
+            const int c = e / nx, x = x0 + e - c * nx;         // x fastest: coalesced NCHW reads
+            float v = 0.f;
+            if (row_in && x >= 1 && x <= W && c < C) v = src[(((size_t)b * C + c) * H + (y - 1)) * W + (x - 1)];
+            tile[c * pitch + (x - x0)] = v;
         }
-        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
-        *reinterpret_cast<float4 *>(grid + (base + x) * cs + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nx * c4n; e += blockDim.x) {
+            const int xl = e / c4n, cg = e - xl * c4n;         // channel group fastest: coalesced grid writes
+            const float4 o = make_float4(tile[(4 * cg) * pitch + xl], tile[(4 * cg + 1) * pitch + xl],
+                                         tile[(4 * cg + 2) * pitch + xl], tile[(4 * cg + 3) * pitch + xl]);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            *reinterpret_cast<float4 *>(grid + (base + x0 + xl) * cs + 4 * cg) = o;
+        }
+        __syncthreads();
     }
     if (amax) mmlf_amax_update_row(mx, amax, row);      // this workgroup wrote grid row `row`
 }
@@ -1109,7 +1119,9 @@ extern "C" int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int
                               void *stream)
 {
     MMLF_CHECK_ARG(nchw && grid && C > 0 && cs % 4 == 0 && C <= cs, "mmlf_pack_nchw: C=%d cs=%d", C, cs);
-    hipLaunchKernelGGL(pack_nchw_kernel, dim3(B * (H + 2)), dim3(256), 0, (hipStream_t)stream, nchw, C, grid, cs, H, W,
+    const size_t lds = (size_t)cs * (PACK_XT | 1) * sizeof(float);
+    MMLF_CHECK_ARG(lds <= 64 * 1024, "mmlf_pack_nchw: cs=%d does not fit the transpose tile", cs);
+    hipLaunchKernelGGL(pack_nchw_kernel, dim3(B * (H + 2)), dim3(256), lds, (hipStream_t)stream, nchw, C, grid, cs, H, W,
                        amax_out);
     return mmlf_launch_status("mmlf_pack_nchw");
 }
