@@ -368,15 +368,15 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int rc = 16 * (k >> 2) + (k & 3);
-            float v = acc[k >> 2][nb][k & 3] * unscale_a * uw + bvn;   // exact: powers of two (1 on the bf16 path)
+            float v = fmaf(acc[k >> 2][nb][k & 3] * unscale_a, uw, bvn);   // the products are exact (powers of two): one rounding, as before
             if (do_relu) v = fmaxf(v, 0.f);
             v = (keep >> rc & 1) ? v : 0.f;
             if (mask_out) mw[k] |= (v > 0.f ? 1u : 0u) << nb;
-            mk[k] = fmaxf(mk[k], fabsf(v));
+            asm("v_max_f32 %0, %1, |%2|" : "=v"(mk[k]) : "v"(mk[k]), "v"(v));   // (fmaxf canonicalises its operand first: two instructions)
             s1 += v;
             s2 = fmaf(v, v, s2);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ob,
-                                                  lo + (unsigned)rc * a.cs_out * 4u + 64 * nb, 0, 0);
+            // row offset in the scalar offset operand, column block in the immediate: no address arithmetic per element
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ob, lo + 64 * nb, (unsigned)rc * a.cs_out * 4u, 0);
         }
         if (stats) {            // BatchNorm statistics: this wave's 32 positions of channel 16*nb + r16
             s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
