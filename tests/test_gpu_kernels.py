@@ -1,5 +1,7 @@
 """GPU parity tests, kernel level: each C-ABI entry point against the CPU oracle on seeded inputs.
 Run on the MI355X box:  python -m pytest tests -m gpu"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -523,3 +525,52 @@ def test_thin_convolution_and_weight_gradient(oracle, cin, cout, pad, variant):
     engine.wgrad(geo, xg, cs_in, cin, gg, cs_out, cout, shift, tgw, tgb, variant, None)
     np.testing.assert_allclose(tgw.cpu().numpy() - 0.5, gw, rtol=1e-4, atol=2e-5 * np.abs(gw).max())
     np.testing.assert_allclose(tgb.cpu().numpy() + 0.25, gb, rtol=1e-4, atol=2e-5 * np.abs(gb).max())
+
+
+def test_sixteen_wave_conv_variant_writes_the_same_bytes(tmp_path):
+    """The 512-position / sixteen-wave kernel of the 70-channel layers (small pitches) indexes masks, statistics and
+    scales by the global 32-position wave, so it must produce the same bytes as the eight-wave kernel: output, ReLU mask
+    words, row maxima and BatchNorm partial sums, compared across two processes (the switch is read once per process)."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from mmlf_amd import engine, _lib
+dev = torch.device('cuda:0')
+B, H, W, cin, cout = 5, 37, 41, 70, 70
+geo = engine.Geometry(B, H, W)
+rs = np.random.RandomState(3)
+cs = engine.cs_of(cin)
+x = geo.buf(cs, dev)
+v = x[:geo.NQ * cs].view(B, geo.R, geo.P, cs)
+v[:, 1:H + 1, 1:W + 1, :cin] = torch.from_numpy(rs.standard_normal((B, H, W, cin)).astype(np.float32) * np.exp(rs.uniform(-6, 6, (B, H, 1, 1))).astype(np.float32)).to(dev)
+x.absmax = geo.amax_of(x, cs)
+w = torch.from_numpy(rs.uniform(-0.5, 0.5, (cout, cin, 2, 2)).astype(np.float32)).to(dev)
+b = torch.from_numpy(rs.uniform(-0.5, 0.5, (cout,)).astype(np.float32)).to(dev)
+pk = engine.pack_filter(w, 0, False)
+y = geo.buf(cs, dev)
+mask = geo.relu_mask(dev)
+engine.conv(geo, x, cs, cin, pk, b, cout, y, cs, 0, H + 1, W + 1, True, mask_out=mask)
+ws = engine._Workspace.get(dev)
+z = geo.buf(cs, dev)
+engine.conv(geo, y, cs, cout, pk, b, cout, z, cs, geo.P + 1, H, W, False, bn_partial=ws.partial)
+nblk = int(_lib.load().mmlf_conv2x2_blocks(cout, B, H, W))
+part = ws.partial[:nblk * 2 * cout].double().view(nblk, 2, cout).sum(0)
+g = geo.buf(cs, dev)
+engine.conv(geo, z, cs, cout, engine.pack_filter(w, 0, True), None, cin, g, cs, 0, H + 1, W + 1, False, mask_in=mask)
+torch.cuda.synchronize()
+np.savez(sys.argv[1], y=y.cpu().numpy(), z=z.cpu().numpy(), g=g.cpu().numpy(), mask=mask.cpu().numpy(),
+         ay=y.absmax.cpu().numpy(), az=z.absmax.cpu().numpy(), part=part.cpu().numpy())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for nw in ('0', '1'):
+        out = str(tmp_path / f'nw{nw}.npz')
+        env = dict(os.environ, MMLF_CONV_NW16=nw)
+        res = subprocess.run([sys.executable, '-c', script, out], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(np.load(out))
+    for key in ('y', 'z', 'g', 'mask', 'ay', 'az'):
+        assert np.array_equal(outs[0][key], outs[1][key]), key
+    # the per-workgroup partial sums are grouped differently (256 vs 512 positions per workgroup): equal after the sum
+    np.testing.assert_allclose(outs[0]['part'], outs[1]['part'], rtol=1e-12)
