@@ -1,6 +1,7 @@
 """Where a conv wave spends its cycles: needs a library built from a conv.hip instrumented with s_memtime at five points of
-the chunk loop (a ConvArgs::tl_out pointer taken from MMLF_TL_PTR; the patch is in the git history of this file's commit
-message, DESIGN.md section 4.6 has the numbers).  python tools/timeline_conv.py with MMLF_HIP_LIB pointing at that build."""
+the chunk loop (a ConvArgs::tl_out pointer taken from MMLF_TL_PTR): tools/timeline_conv.patch, applied to a COPY of
+mmlf_amd/csrc/conv.hip and linked with elementwise.o into a scratch library; MMLF_HIP_LIB points this script at it.
+DESIGN.md section 4.6 has the numbers."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from mmlf_amd import engine, _lib
