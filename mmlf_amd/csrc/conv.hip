@@ -482,6 +482,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     // pipeline buffers: two; the sixteen-wave variant has the LDS for a ring of MMLF_RING16, with the DMA of chunk
     // c + D - 1 issued during chunk c and a counted wait that leaves the newest D - 2 chunks' pieces in flight
     constexpr int D = NW == 16 ? MMLF_RING16 : 2;
+    // EARLY: the chunk's barrier stands two column blocks before its end (the weight fragments of those two blocks are
+    // in registers by then): behind it the wave requests the NEXT chunk's activation and first weight fragments and runs
+    // its last twelve MFMAs while they arrive -- the LDS latency of the chunk head (both waves of a SIMD stand in it at
+    // once: 12 % of a 280-wide chunk by the wave's own clock) is off the critical path.  Needs G % 3 == 0 (the rotating
+    // fragment slots line up across chunks) and enough column blocks behind the DMA issue for the pieces to land.
+    constexpr bool EARLY = PL == 2 && G % 3 == 0 && G >= 9;   // (the three-plane build has no registers to spare for it)
     // A: [640 slots][channel half(2)] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
     // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
     // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
@@ -570,6 +576,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             X6_DMA_PIECE(tl, c, buf, (slot) * PER_SLOT + k_);                                            \
     } while (0)
 #define X6_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define X6_CHUNK_WAIT()                                                                                  \
+    do {                                                                                                 \
+        if (D > 2 && more) {      /* in-order counter: everything but this wave's newest (D - 2) x n_mine pieces has landed */ \
+            static_assert(PER_WAVE <= 3 || D == 2, "counted waits are written for up to three pieces per wave");             \
+            if (n_mine == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (D - 2)) : "memory");            \
+            else if (n_mine == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 2)) : "memory");       \
+            else if (n_mine == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (D - 2)) : "memory");       \
+            else X6_DMA_WAIT();                                                                          \
+        } else {                                                                                         \
+            X6_DMA_WAIT();                                                                               \
+        }                                                                                                \
+    } while (0)
 
     // Persistent over tiles: the chunk pipeline runs on across tile boundaries, so the DMA of the next
     // tile's first chunk is in flight while this tile's last chunk multiplies and its epilogue stores.
@@ -603,6 +621,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     X6_DMA_WAIT();
     __syncthreads();
     int buf = 0;
+    float4 ra[2][2];                                           // activation fragments of the chunk about to be split
+    bf16x8 bq[3][PL];                                          // rotating [slot][plane] weight fragments
+    const int a_lane = 2 * (32 * w + r16 + (q4 & 1) + (q4 >> 1) * a.seg_slot);   // float4 index: + 32*mb + half
+    const int b_lane = q4 * NP + r16;                                            // bf16x8 index: + pl*4*NP + 16*nb
+    if constexpr (EARLY) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) ra[mb][hf] = lds[a_lane + 32 * mb + hf];
+#pragma unroll
+        for (int g0 = 0; g0 < 2; ++g0)
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+                bq[g0][pl] = (reinterpret_cast<const bf16x8 *>(lds + A_F4) + b_lane)[pl * 4 * NP + 16 * g0];
+    }
 
     while (tile < ntiles) {
         // opaque to the optimiser: keeps the per-piece address terms derived from it from being hoisted out
@@ -611,20 +644,23 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         const bool more = ntile < ntiles;
         const int fb = buf == 0 ? D - 1 : buf - 1;             // the buffer multiplied last: free for chunk c + D - 1
         const float4 *base = lds + buf * BUF_F4;
+        const float4 *nbase = lds + (buf + 1 == D ? 0 : buf + 1) * BUF_F4;   // the next chunk's buffer
         // lane (r16, q4): row r16 of a 16-position block, tap q4 -> slot offset (q4&1) + (q4>>1)*seg_slot
-        const float4 *ap = base + 2 * (32 * w + r16 + (q4 & 1) + (q4 >> 1) * a.seg_slot);   // + 32*mb + half
-        const bf16x8 *bp = reinterpret_cast<const bf16x8 *>(base + A_F4) + q4 * NP + r16;   // + pl*4*NP + 16*nb
+        const float4 *ap = base + a_lane;                                                    // + 32*mb + half
+        const bf16x8 *bp = reinterpret_cast<const bf16x8 *>(base + A_F4) + b_lane;           // + pl*4*NP + 16*nb
+        const bf16x8 *bpn = reinterpret_cast<const bf16x8 *>(nbase + A_F4) + b_lane;
+        const bool tile_end = c + 1 == a.nchunk;
 
-        float4 ra[2][2];
+        if constexpr (!EARLY) {
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) ra[mb][hf] = ap[32 * mb + hf];
-        bf16x8 bq[3][PL];                                      // rotating [slot][plane] weight fragments
+                for (int hf = 0; hf < 2; ++hf) ra[mb][hf] = ap[32 * mb + hf];
 #pragma unroll
-        for (int g0 = 0; g0 < 2; ++g0)
+            for (int g0 = 0; g0 < 2; ++g0)
 #pragma unroll
-            for (int pl = 0; pl < PL; ++pl) bq[g0][pl] = bp[pl * 4 * NP + 16 * g0];
+                for (int pl = 0; pl < PL; ++pl) bq[g0][pl] = bp[pl * 4 * NP + 16 * g0];
+        }
         bf16x8 asp[2][PL];                                     // [row block][plane] split activations
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
@@ -648,9 +684,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            if (EARLY && g == G - 2) {
+                // every LDS read of this chunk has been requested (weights run two column blocks ahead): wait for them and
+                // for the next chunk's DMA pieces, pass the barrier, then ask for the next chunk's activations
+                X6_CHUNK_WAIT();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (!tile_end) {            // (at a tile's end they would live through the epilogue: requested behind it)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) ra[mb][hf] = (nbase + a_lane)[32 * mb + hf];
+                }
+            }
             if (g + 2 < G) {
 #pragma unroll
                 for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bp[pl * 4 * NP + 16 * (g + 2)];
+            } else if (EARLY && !tile_end) {   // behind the barrier: the next chunk's first two column blocks (G % 3 == 0)
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bpn[pl * 4 * NP + 16 * (g + 2 - G)];
             }
             __builtin_amdgcn_sched_barrier(0);
             if (more) {   // both slots of a wave in one go, as early as the buffer is free; the two waves of a SIMD apart
@@ -689,15 +741,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
         // the next chunk's DMA pieces must have landed before the barrier; at a tile end wait for them
         // BEFORE the epilogue, so that its stores (same counter) stay in flight across the barrier
-        if (D > 2 && more) {      // in-order counter: everything but this wave's newest (D - 2) x n_mine pieces has landed
-            static_assert(PER_WAVE <= 3 || D == 2, "counted waits are written for up to three pieces per wave");
-            if (n_mine == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (D - 2)) : "memory");
-            else if (n_mine == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 2)) : "memory");
-            else if (n_mine == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (D - 2)) : "memory");
-            else X6_DMA_WAIT();
-        } else {
-            X6_DMA_WAIT();
-        }
+        if constexpr (!EARLY) X6_CHUNK_WAIT();
         if (++c == a.nchunk) {
             const ConvArgs e = late_args(); // epilogue-only arguments: loaded here, dead again at the barrier
             float next_amax = 0.f;          // the next tile's row maxima: loads in flight during the epilogue
@@ -720,10 +764,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                     unscale_a = 1.f / scale_a;
                 }
             }
+            if constexpr (EARLY) {          // the next tile's first fragments (its chunk 0 passed the barrier above)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) ra[mb][hf] = (nbase + a_lane)[32 * mb + hf];
+#pragma unroll
+                for (int g0 = 0; g0 < 2; ++g0)
+#pragma unroll
+                    for (int pl = 0; pl < PL; ++pl) bq[g0][pl] = bpn[pl * 4 * NP + 16 * g0];
+            }
         }
-        __syncthreads();
+        if constexpr (!EARLY) __syncthreads();
         buf = buf + 1 == D ? 0 : buf + 1;
     }
+    if constexpr (EARLY) __syncthreads();                       // orders the last tile's wave sums
     const ConvArgs e = late_args();
     if (e.out_amax) mmlf_amax_update(run_max, e.out_amax);      // at most one atomic per wave per launch
     if (e.bn_partial) {                                         // the loop's last barrier ordered the wave sums
@@ -738,6 +793,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
 #undef X6_DMA_PIECE
 #undef X6_DMA_SLOT
 #undef X6_DMA_WAIT
+#undef X6_CHUNK_WAIT
 }
 
 
