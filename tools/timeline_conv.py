@@ -4,6 +4,7 @@ mmlf_amd/csrc/conv.hip and linked with elementwise.o into a scratch library; MML
 DESIGN.md section 4.6 has the numbers."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
+os.environ.setdefault('MMLF_HIP_LIB', os.path.join(os.getcwd(), 'scratch/tl/lib_tl.so'))
 from mmlf_amd import engine, _lib
 dev = torch.device('cuda:0')
 B, H, W = 512, 96, 96
