@@ -1457,6 +1457,23 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         if (c_begin + 1 < c_end) WW_GLOAD(c_begin + 1);
         __syncthreads();
         int buf = 0;
+        // EARLY (as in the conv kernel): the chunk's barrier stands two column blocks before its end -- every staging
+        // store of the chunk is out by then (one piece per column block, NA + NG <= NBH - 2) and every fragment read
+        // requested -- and behind it the wave asks for the NEXT chunk's first gradient fragments (the rotating slots run
+        // on, NBH % 3 == 0) and its first two activation row blocks, which arrive under the last 2 x 3 x MB MFMAs.
+        constexpr bool EARLY = PL == 2 && NBH % 3 == 0 && NA + NG <= NBH - 2 && MB >= 2;
+        bf16x8 af[MB][PL], gfr[3][PL], afp[2][PL];
+        if constexpr (EARLY) {
+            const char *cur0 = smem;
+#pragma unroll
+            for (int g0 = 0; g0 < 2; ++g0)
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) gfr[g0][pl] = tr_frag(cur0 + g_off + pl * G_PLANE + 32 * g0, 4 * ROWG);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int pl = 0; pl < PL; ++pl) af[mb][pl] = tr_frag(cur0 + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);
+        }
         // One chunk: gradient fragments are read two column blocks ahead (three register sets); with STAGE the
         // registers holding chunk c+1 are split and stored into the other buffer, one piece per column
         // block, branch-free so that the stores interleave with the MFMAs -- and the register a piece leaves is
@@ -1469,17 +1486,28 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     do {                                                                                                     \
         const char *cur = smem + buf * BUF_BYTES;                                                            \
         char *nxt = smem + (buf ^ 1) * BUF_BYTES;                                                            \
-        bf16x8 af[MB][PL], gfr[3][PL];                                                                         \
-        _Pragma("unroll") for (int g0 = 0; g0 < 2; ++g0)                                                     \
-            _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                                 \
-                gfr[g0][pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * g0, 4 * ROWG);                       \
-        _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                                    \
+        if (!EARLY) {                                                                                        \
+            _Pragma("unroll") for (int g0 = 0; g0 < 2; ++g0)                                                 \
+                _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                             \
+                    gfr[g0][pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * g0, 4 * ROWG);                   \
+        }                                                                                                    \
+        _Pragma("unroll") for (int mb = EARLY ? 2 : 0; mb < MB; ++mb)                                        \
             _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                                 \
                 af[mb][pl] = tr_frag(cur + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);                        \
         _Pragma("unroll") for (int nb = 0; nb < NBH; ++nb) {                                                 \
+            if (EARLY && (STAGE) && nb == NBH - 2) {                                                         \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* my staging stores and fragment reads */ \
+                __syncthreads();                                                                             \
+                _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                             \
+                    _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                         \
+                        afp[mb][pl] = tr_frag(nxt + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);               \
+            }                                                                                                \
             if (nb + 2 < NBH) {                                                                              \
                 _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                             \
                     gfr[(nb + 2) % 3][pl] = tr_frag(cur + g_off + pl * G_PLANE + 32 * (nb + 2), 4 * ROWG);   \
+            } else if (EARLY && (STAGE)) {                                                                   \
+                _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                             \
+                    gfr[(nb + 2) % 3][pl] = tr_frag(nxt + g_off + pl * G_PLANE + 32 * (nb + 2 - NBH), 4 * ROWG); \
             }                                                                                                \
             if (STAGE) {                                                                                     \
                 if (nb < NA) {                                                                               \
@@ -1493,13 +1521,17 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
             _Pragma("unroll") for (int term = 0; term < (PL == 3 ? 6 : 3); ++term)                           \
                 WW_TERM(gfr[nb % 3], term_a<PL>(term), term_b<PL>(term));                                    \
         }                                                                                                    \
+        if (EARLY && (STAGE)) {                                                                              \
+            _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                 \
+                _Pragma("unroll") for (int pl = 0; pl < PL; ++pl) af[mb][pl] = afp[mb][pl];                   \
+        }                                                                                                    \
     } while (0)
         static_assert(NA + NG <= NBH, "one staging piece per column block");
         for (int c = c_begin; c + 1 < c_end; ++c) {
             wgrad_chunk_scale<PL>(a, c + 1, st_sa, st_sg);
             const bool reload = c + 2 < c_end;
             WW_CHUNK(true, reload);
-            __syncthreads();
+            if constexpr (!EARLY) __syncthreads();
             buf ^= 1;
         }
         {
