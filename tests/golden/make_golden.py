@@ -22,6 +22,9 @@ Groups:
   G8  round-2 additions: padded / multimodal loss gradients, DPP full-size train step, eval-mode training
       (--train_eval_mode), and a checkpoint.pt written by the reference's own ModelSaver + torch.optim.Adam
       with the state one resumed step later (g9_checkpoint.pt is a data file: tensors and hyper-parameters).
+  G10 round 3: the bytes the reference's pfm.save writes (grey, colour, flipped views as HCI4D.save_batch passes
+      them) and what its pfm.load reads back; the float64 run of the G2 BASE / UPR train step (the reference module in
+      .double()): loss, depth and the same gradient samples as G2, as the yardstick for float32-level gradient parity.
 """
 import os
 import sys
@@ -464,7 +467,67 @@ def g8_extras():
     print('G9 checkpoint', os.path.getsize(os.path.join(HERE, 'g9_checkpoint.pt')), 'bytes; resumed loss', l3)
 
 
+def g10_pfm_and_f64():
+    import tempfile
+    from mmlf.utils import pfm as ref_pfm
+    rs = np.random.RandomState(31)
+    rec = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        cases = {'grey': rs.randn(7, 5).astype(np.float32),
+                 'grey1': rs.randn(4, 6, 1).astype(np.float32),
+                 'colour': rs.rand(6, 9, 3).astype(np.float32),
+                 # hci4d.py:358-366: save_batch writes np.flip(x.copy(), 0), a negatively strided view
+                 'flipped': np.flip(rs.randn(8, 8).astype(np.float32).copy(), 0),
+                 'scaled': (100.0 * rs.randn(3, 4)).astype(np.float32)}
+        for name, arr in cases.items():
+            fn = os.path.join(tmp, name + '.pfm')
+            if name == 'scaled':
+                ref_pfm.save(fn, arr, scale=2.5)
+            else:
+                ref_pfm.save(fn, arr)
+            rec[f'{name}/array'] = np.ascontiguousarray(arr)
+            rec[f'{name}/bytes'] = np.frombuffer(open(fn, 'rb').read(), dtype=np.uint8).copy()
+            rec[f'{name}/loaded'] = ref_pfm.load(fn)
+        # a big-endian file (positive scale), which only load has to understand
+        be = rs.randn(5, 3).astype('>f4')
+        fn = os.path.join(tmp, 'be.pfm')
+        with open(fn, 'wb') as f:
+            f.write(b'Pf\n3 5\n1.000000\n')
+            be.tofile(f)
+        rec['bigendian/bytes'] = np.frombuffer(open(fn, 'rb').read(), dtype=np.uint8).copy()
+        rec['bigendian/loaded'] = ref_pfm.load(fn)
+    np.savez_compressed(os.path.join(HERE, 'g10_pfm.npz'), **rec)
+    print('G10 pfm', {k: v.shape for k, v in rec.items() if k.endswith('bytes')})
+
+    # float64 run of the G2 train step (same weights, inputs, mask as g2_full): what float32 parity is measured against
+    for variant in ('base', 'upr'):
+        kw = dict(BASE_KW, **VARIANTS[variant])
+        model, state = build_ref(kw, seed=21)
+        model = model.double()
+        stacks, gt, mask = synth.synth_inputs(2, 96, seed=8)
+        m = train_mask(mask)
+        model.train()
+        model.zero_grad()
+        out = model(*[torch.from_numpy(s).double() for s in stacks])
+        loss = loss_for(variant, out, torch.from_numpy(gt).double(), m, kw)
+        loss.backward()
+        rec = {'train_mean': out['mean'].detach().numpy(), 'loss': loss.detach().numpy()}
+        if variant == 'upr':
+            rec['train_logvar'] = out['logvar'].detach().numpy()
+        for n, p in model.named_parameters():
+            g = p.grad.numpy()
+            rec[f'grad_s/{n}'] = sample(g) if g.size > 4096 else g.copy()
+        for n, v in model.state_dict().items():
+            if 'running' in n:
+                rec[f'post/{n}'] = v.numpy().copy()
+        np.savez_compressed(os.path.join(HERE, f'g10_full_{variant}_f64.npz'), **rec)
+        print('G10 f64', variant, float(loss))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'g10':
+        g10_pfm_and_f64()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g8':
         g8_extras()
         sys.exit(0)
@@ -481,6 +544,7 @@ if __name__ == '__main__':
     g6_multimodal()
     g7_patch_pipeline()
     g8_extras()
+    g10_pfm_and_f64()
     sizes = {f: os.path.getsize(os.path.join(HERE, f)) for f in sorted(os.listdir(HERE))
              if f.endswith('.npz')}
     print(sizes)
