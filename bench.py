@@ -135,6 +135,47 @@ def extra_leg(variant, B, patch, dev, steps, peak):
     return out
 
 
+def autograd_leg(variant, B, patch, dev, steps, ref_ms):
+    """The loop INTEGRATION.md section 1 advertises as the drop-in surface -- reference mmlf/train/cli.py:243-258 --
+    instead of TrainStep: optimizer.zero_grad(); model(h, v, i, d) with the head outputs materialised (the UPR
+    posterior: 2 GB per step); the mmlf_amd.loss module; loss.backward() through the one autograd node;
+    torch.optim.Adam.step()."""
+    from mmlf_amd import loss as loss_mod
+    from mmlf_amd.feed_forward import FeedForward
+    kw = dict(BASE_KW, **KW_EXTRA[variant])
+    torch.manual_seed(0)
+    model = FeedForward(**kw).to(dev)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    stacks = [torch.rand((B, 9, 3, patch, patch), device=dev, generator=gen) for _ in range(4)]
+    gt = 4.0 * torch.rand((B, patch, patch), device=dev, generator=gen) - 2.0
+    mask = (torch.ones((B, patch, patch), dtype=torch.int32) * loss_mod.create_mask_margin((B, patch, patch), 11)).to(dev)
+    crit = loss_mod.ImprovedUncertaintyL1Loss() if variant == 'upr' else loss_mod.MaskedL1Loss()
+
+    def one():
+        opt.zero_grad()
+        out = model(*stacks)
+        val = crit(out, gt, mask, None) if variant == 'upr' else crit(out, gt, mask)
+        val.backward()
+        opt.step()
+        return val
+
+    one()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        val = one()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    ms = 1e3 * dt / steps
+    res = {'value': round(B * steps / dt, 2), 'unit': 'patches/s', 'steps': steps, 'ms_per_step': round(ms, 2),
+           'loss': round(float(val), 6), 'vs_train_step': round(ref_ms / ms, 4) if ref_ms else None}
+    del model, opt, stacks, gt, mask
+    torch.cuda.empty_cache()
+    return res
+
+
 def ese_leg(dev, peak, size=512):
     """BASELINE.json configs[4] on one GPU: one 512x512 light field through the 70-member Ensamble (eval)"""
     from mmlf_amd.ensamble import Ensamble
@@ -210,7 +251,9 @@ def main():
         step(*stacks, gt, mask, it)
         it += 1
     sync()
-    engine.PROFILE = []           # (tag, flops, start_event, end_event) of the dominant conv launches
+    engine.PROFILE = []           # (tag, flops, start_event, end_event) of the 280-wide conv / weight-gradient launches
+    if step.buckets is not None:
+        step.buckets.wait_events = []
     t0 = time.time()
     for _ in range(args.steps):
         loss = step(*stacks, gt, mask, it)
@@ -233,6 +276,7 @@ def main():
         dt1 = time.time() - t1
         p1, engine.PROFILE = engine.PROFILE, None
         engine.CONV_MODE = mode
+        p1 = [r for r in p1 if r[0] == 'conv']
         s1 = sum(e0.elapsed_time(e1) for _, _, e0, e1 in p1) * 1e-3
         a1 = sum(f for _, f, _, _ in p1) / s1 / 1e12 if s1 > 0 else 0.0
         f32_leg = {'value': round(args.global_batch * 2 / dt1, 3), 'unit': 'patches/s', 'steps': 2,
@@ -244,8 +288,17 @@ def main():
     dt = float(tmax)
     loss_val = float(loss)
 
+    allreduce_ms = None
+    if step.buckets is not None and step.buckets.wait_events:
+        # per step: how long the compute stream stood behind the bucket all-reduces after backward had been enqueued
+        ar = torch.tensor([sum(a.elapsed_time(b) for a, b in step.buckets.wait_events) / len(step.buckets.wait_events)],
+                          dtype=torch.float64, device=dev)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        allreduce_ms = float(ar)
     if rank == 0:
         value = args.global_batch * args.steps / dt
+        wprof = [r for r in prof if r[0].startswith('wgrad')]
+        prof = [r for r in prof if r[0] == 'conv']
         secs = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
         flops = sum(f for _, f, _, _ in prof)
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
@@ -276,6 +329,27 @@ def main():
                          'algorithmic_bytes': round(2.0 * B * 98 * 98 * 280 * 4) if args.patch == 96 else None,
                          'launches': len(prof), 'avg_ms': round(1e3 * secs / max(1, len(prof)), 3)},
         }
+        if wprof:      # the 280-wide weight gradient: the largest single kernel of the step, same peak definition
+            wsecs = sum(e0.elapsed_time(e1) for _, _, e0, e1 in wprof) * 1e-3
+            wach = sum(f for _, f, _, _ in wprof) / wsecs / 1e12
+            side = [r for r in wprof if r[0] == 'wgrad_side']
+            main = [r for r in wprof if r[0] == 'wgrad']
+            avg = lambda rs: round(sum(e0.elapsed_time(e1) for _, _, e0, e1 in rs) / len(rs), 3) if rs else None
+            wname = f'wgrad4tap_x6w_kernel<3, 9, {2 if passes == 3 else 3}>' if split else 'wgrad4tap_kernel<9>'
+            line['roofline_wgrad'] = {
+                'bound': 'mfma', 'achieved': round(wach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                'frac': round(wach / peak, 4), 'traffic': pmc_traffic(wname.split('<')[0]) if args.global_batch == 512 and world == 1 else None,
+                'kernel': wname + ' + scales / reduce launches (280->280 weight + bias gradient, in the step: the '
+                                  'conv1 gradients run on a side stream beside the BatchNorm-backward kernels)',
+                'launches': len(wprof), 'avg_ms': round(1e3 * wsecs / len(wprof), 3),
+                'avg_ms_main_stream': avg(main), 'avg_ms_side_stream': avg(side),
+                'algorithmic_bytes': round(2.0 * B * 98 * 98 * 280 * 4) if args.patch == 96 else None}
+        if world > 1:
+            line['config']['buckets'] = len(step.buckets.ranges)
+            line['config']['gradient_bytes'] = int(step.grad.numel()) * 4
+            line['allreduce_ms'] = None if allreduce_ms is None else round(allreduce_ms, 3)
+            line['allreduce_note'] = ('per step, max over ranks: time the compute stream waits for the bucket all-reduces '
+                                      'after backward is enqueued (0 = fully overlapped with backward)')
         if args.backend != 'nccl':
             line['config']['backend'] = args.backend + ' (rehearsal: not an xGMI measurement)'
         if f32_leg is not None:
@@ -288,6 +362,12 @@ def main():
                 if key != args.variant:
                     line[key] = extra_leg(variant, b, 96, dev, n, peak)
             line['shard64']['note'] = 'the per-GPU share of the bs=512 batch on 8 GPUs (configs[3] shape), one GPU, no collective'
+            line['shard64']['vs_bs512'] = round(line['shard64']['value'] / value, 4)
+            # the reference's own loop shape on the drop-in module (autograd + torch.optim.Adam), driver-timed
+            line['autograd_loop'] = {v: autograd_leg(v, 512, 96, dev, 2, line[v]['ms_per_step'] if v in line else 1e3 * dt / args.steps)
+                                     for v in ('base', 'upr')}
+            line['autograd_loop']['note'] = ('model(h,v,i,d) -> mmlf_amd.loss module -> loss.backward() -> torch.optim.Adam.step() '
+                                             '(mmlf/train/cli.py:243-258), head outputs materialised; vs_train_step = TrainStep ms / this ms')
             line['ese'] = ese_leg(dev, peak)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.patch)

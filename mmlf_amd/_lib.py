@@ -63,6 +63,7 @@ SIGNATURES = {
     'mmlf_ensamble_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
+ABI_VERSION = 3          # include/mmlf_hip.h MMLF_ABI_VERSION: bumped whenever an entry point's arguments change
 _lib = None
 
 
@@ -75,6 +76,11 @@ def load():
                 f'{LIB_PATH} not found: build it with `python -m mmlf_amd.csrc.build` '
                 '(the HIP path has no CPU fallback)')
         lib = ctypes.CDLL(LIB_PATH)
+        # a stale or A/B build that still exports the names would be called with shifted arguments: refuse it here
+        if not hasattr(lib, 'mmlf_abi_version') or lib.mmlf_abi_version() != ABI_VERSION:
+            got = lib.mmlf_abi_version() if hasattr(lib, 'mmlf_abi_version') else None
+            raise RuntimeError(f'{LIB_PATH} implements ABI version {got}, this package needs {ABI_VERSION}: rebuild it '
+                               'with `python -m mmlf_amd.csrc.build --force`')
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

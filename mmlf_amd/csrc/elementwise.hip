@@ -302,24 +302,24 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
 }
 
 // NCHW <-> grid
-#define PACK_XT 128   // positions per transpose tile of pack_nchw_kernel
+#define PACK_XT 128   // positions per transpose tile of pack_nchw_kernel (halved until the tile fits 64 KB: wide tensors)
 __global__ __launch_bounds__(256) void pack_nchw_kernel(const float *__restrict__ src, int C,
                                                         float *__restrict__ grid, int cs, int H, int W,
-                                                        float *__restrict__ amax)
+                                                        float *__restrict__ amax, int xt)
 {
     // a transpose through LDS: the NCHW planes are read with x across the lanes, the grid row is written with the channel
     // groups across the lanes (whole 16*c4n-byte position rows per instruction instead of one 16-byte piece per line)
-    extern __shared__ float tile[];            // [cs][PACK_XT | 1]: channel-major, odd pitch (conflict-free both ways)
+    extern __shared__ float tile[];            // [cs][xt | 1]: channel-major, odd pitch (conflict-free both ways)
     float mx = 0.f;
     const int P = W + 2, R = H + 2;
     const int row = blockIdx.x;
     const int b = row / R, y = row - b * R;
     const size_t base = (size_t)row * P;
     const int c4n = cs / 4;
-    constexpr int pitch = PACK_XT | 1;
+    const int pitch = xt | 1;
     const bool row_in = (y >= 1 && y <= H);
-    for (int x0 = 0; x0 < P; x0 += PACK_XT) {                  // the row in pieces of PACK_XT positions
-        const int nx = min(PACK_XT, P - x0);
+    for (int x0 = 0; x0 < P; x0 += xt) {                       // the row in pieces of xt positions
+        const int nx = min(xt, P - x0);
         for (int e = threadIdx.x; e < cs * nx; e += blockDim.x) {
             const int c = e / nx, x = x0 + e - c * nx;         // x fastest: coalesced NCHW reads
             float v = 0.f;
@@ -1119,10 +1119,12 @@ extern "C" int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int
                               void *stream)
 {
     MMLF_CHECK_ARG(nchw && grid && C > 0 && cs % 4 == 0 && C <= cs, "mmlf_pack_nchw: C=%d cs=%d", C, cs);
-    const size_t lds = (size_t)cs * (PACK_XT | 1) * sizeof(float);
+    int xt = PACK_XT;            // DPP with many views packs a gradient of 4*views*3 channels (132 at 11 views)
+    while (xt > 4 && (size_t)cs * (xt | 1) * sizeof(float) > 64 * 1024) xt >>= 1;
+    const size_t lds = (size_t)cs * (xt | 1) * sizeof(float);
     MMLF_CHECK_ARG(lds <= 64 * 1024, "mmlf_pack_nchw: cs=%d does not fit the transpose tile", cs);
     hipLaunchKernelGGL(pack_nchw_kernel, dim3(B * (H + 2)), dim3(256), lds, (hipStream_t)stream, nchw, C, grid, cs, H, W,
-                       amax_out);
+                       amax_out, xt);
     return mmlf_launch_status("mmlf_pack_nchw");
 }
 

@@ -60,15 +60,18 @@ class Geometry:
 class _Workspace:
     """Scratch that is reused across calls (stream-ordered, single stream), one per (device, calling thread):
     nn.DataParallel drives replicas from one thread per device -- and nothing stops two of them from sharing a
-    device -- while autograd's backward runs on its own thread per device."""
-    _cache = {}
+    device -- while autograd's backward runs on its own thread per device.  Kept in thread-local storage, so a
+    workspace (an 8 MB partial-sum buffer, a side stream, up to a few hundred MB of weight-gradient scratch) dies
+    with its thread: DataParallel.parallel_apply starts fresh threads on every forward."""
+    _tls = threading.local()
 
     @classmethod
     def get(cls, device):
-        key = (device.type, device.index, threading.get_ident())
-        ws = cls._cache.get(key)
+        table = cls._tls.__dict__.setdefault('table', {})
+        key = (device.type, device.index)
+        ws = table.get(key)
         if ws is None:
-            ws = cls._cache[key] = cls(device)
+            ws = table[key] = cls(device)
         return ws
 
     def __init__(self, device):
@@ -128,7 +131,7 @@ def pack_filter(w, variant, dgrad):
     return out
 
 
-PROFILE = None   # bench.py sets this to a list to time the dominant conv launches with HIP events
+PROFILE = None   # bench.py sets this to a list to time the 280-wide conv / weight-gradient launches with HIP events
 
 
 def _amax_of(geo, t, cs):
@@ -156,21 +159,32 @@ OVERLAP_WGRAD = os.environ.get('MMLF_OVERLAP_WGRAD', '1') != '0'
 THIN_MAX_N, THIN_MIN_K = 2, 64     # mmlf_conv2x2_thin: at most 2 output channels over at least 64 input channels
 
 
-def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace):
-    """weight + bias gradient, accumulated into gw / gb"""
+def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace, side=False):
+    """weight + bias gradient, accumulated into gw / gb (side: the launch goes to the side stream and must not share
+    scratch with main-stream launches)"""
     if cout <= THIN_MAX_N and cin >= THIN_MIN_K and cs_in <= 512:
         # a matrix-vector product (the BASE / UPR head): plain float32 FMAs, bound by reading x once
-        ws = _Workspace.get(x.device).scratch('thin_wgrad', int(_lib.load().mmlf_conv2x2_wgrad_thin_workspace_floats(cin)))
+        ws = _Workspace.get(x.device).scratch('thin_wgrad_side' if side else 'thin_wgrad', int(_lib.load().mmlf_conv2x2_wgrad_thin_workspace_floats(cin)))
         call('mmlf_conv2x2_wgrad_thin', ptr(x), cs_in, cin, ptr(g), cs_g, cout, g_shift, ptr(gw), ptr(gb), variant, 1,
              ptr(ws), geo.B, geo.H, geo.W, _lib.stream_ptr())
         return
     args = (ptr(x), cs_in, cin, ptr(g), cs_g, cout, g_shift, ptr(gw), ptr(gb), variant, 1, ptr(workspace),
             geo.B, geo.H, geo.W)
+    prof = PROFILE is not None and cin >= 256 and cout >= 256
+    if prof:      # events on the stream the launch goes to (the side stream for the overlapped ones)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     if CONV_MODE == 'f16x3':
         ax, ag = _amax_of(geo, x, cs_in), _amax_of(geo, g, cs_g)
         call('mmlf_conv2x2_wgrad_h2', *args, ptr(ax), ptr(ag), _lib.stream_ptr())
     else:
         call('mmlf_conv2x2_wgrad_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad', *args, _lib.stream_ptr())
+    if prof:
+        e1.record()
+        # algorithmic FLOPs: the convolution's valid output positions x Cout x 4 taps x Cin, 2 FLOP per MAC (the
+        # gradient of a pad-1 convolution lives at grid offset 0 with extent (H+1, W+1), of a pad-0 one at (1, 1))
+        vh, vw = (geo.H + 1, geo.W + 1) if g_shift == 0 else (geo.H, geo.W)
+        PROFILE.append(('wgrad_side' if side else 'wgrad', 2.0 * geo.B * vh * vw * cout * 4 * cin, e0, e1))
 
 
 def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0,
@@ -393,7 +407,7 @@ class Trunk:
             with torch.cuda.stream(ws.side):
                 ws.side.wait_event(ready)
                 wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'],
-                      var, ws.wgrad_ws(geo, spec.cin, C, side=True))
+                      var, ws.wgrad_ws(geo, spec.cin, C, side=True), side=True)
                 done = ws.side.record_event()
             # x and dy are read by the side stream: the caller keeps them alive until the main stream has waited
             # for `done` (no record_stream: deferred reuse makes the caching allocator grow and stall)

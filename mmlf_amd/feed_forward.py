@@ -7,7 +7,7 @@ checkpoints load unchanged and the reference's train / validate drivers can use 
 On CUDA (= HIP on ROCm) tensors with the default flags (k=2, BatchNorm, four streams) the whole
 trunk runs in hand-written gfx950 kernels through the C ABI (engine.Trunk); there is no fallback on
 that path: a missing libmmlf_hip.so raises.  CPU tensors, and the non-default flags the README
-recipes never use (model_cross, odd ksize, model_no_batchnorm), run the module tree with stock
+recipes never use (model_cross, odd ksize, model_no_batchnorm, model_unet), run the module tree with stock
 torch ops ("plumbing path": BASELINE.json configs[0], CPU tests, gloo rehearsal).
 """
 import numpy as np
@@ -34,6 +34,58 @@ def _conv_block(cin, cout, ksize, pad1, pad2, bn, momentum):
             layers.append(nn.BatchNorm2d(cout, momentum=momentum))
         layers.append(nn.ReLU())
     return nn.Sequential(*layers)
+
+
+class _UNetStage(nn.Module):
+    """two 3x3 conv + ReLU + BatchNorm pairs; parameter names `block.{0,2,3,5}` as in reference unet.py:81-101"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.block = nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1), nn.ReLU(), nn.BatchNorm2d(cout),
+                                   nn.Conv2d(cout, cout, 3, padding=1), nn.ReLU(), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        return self.block(x)
+
+
+class _UNetUp(nn.Module):
+    """transposed-conv upsampling, centre-cropped skip connection, conv stage (reference unet.py:104-135)"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2)
+        self.conv_block = _UNetStage(cin, cout)
+
+    def forward(self, x, skip):
+        x = self.up(x)
+        h, w = x.shape[2:]
+        y0, x0 = (skip.shape[2] - h) // 2, (skip.shape[3] - w) // 2
+        return self.conv_block(torch.cat([x, skip[:, :, y0:y0 + h, x0:x0 + w]], 1))
+
+
+class _UNetTail(nn.Module):
+    """--model_unet: the merge network as a depth-5 U-Net (reference feed_forward.py:189-204, unet.py:8-78 with
+    padding=True, batch_norm=True, wf=6, 'upconv').  Stock torch ops only: no README recipe uses the flag, so it is
+    outside the accelerated path ("stays accepted and takes a stock-torch fallback"); the
+    state_dict keys (`down_path.i.block.*`, `up_path.i.{up,conv_block.block}.*`, `last.*`) match the reference's."""
+
+    def __init__(self, cin, cout, depth=5, wf=6):
+        super().__init__()
+        widths = [2 ** (wf + i) for i in range(depth)]
+        self.down_path = nn.ModuleList(_UNetStage(a, b) for a, b in zip([cin] + widths[:-1], widths))
+        self.up_path = nn.ModuleList(_UNetUp(widths[i + 1], widths[i]) for i in reversed(range(depth - 1)))
+        self.last = nn.Conv2d(widths[0], cout, kernel_size=1)
+
+    def forward(self, x):
+        skips = []
+        for stage in self.down_path[:-1]:
+            x = stage(x)
+            skips.append(x)
+            x = nn.functional.max_pool2d(x, 2)
+        x = self.down_path[-1](x)
+        for up in self.up_path:
+            x = up(x, skips.pop())
+        return self.last(x)
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -71,8 +123,6 @@ class FeedForward(nn.Module):
                  model_cross, model_uncert, model_unet, model_discrete, model_no_batchnorm,
                  model_batchnorm_momentum, val_disp_min, val_disp_max, **kwargs):
         super().__init__()
-        if model_unet:
-            raise NotImplementedError('model_unet is outside the accelerated path (SURVEY.md section 2)')
         assert model_in_blocks >= 1 and model_out_blocks >= 1
         self.ksize, self.chs, self.views = model_ksize, model_chs, model_views
         self.cross, self.uncert, self.discrete = model_cross, model_uncert, model_discrete
@@ -96,14 +146,19 @@ class FeedForward(nn.Module):
             self.in_net_id = in_net()
         c = (2 if model_cross else 4) * model_chs
         oc = 2 if model_uncert else (self.steps if model_discrete else 1)
-        blocks = [_conv_block(c, c, model_ksize, pad1, pad2, bn, model_batchnorm_momentum)
-                  for _ in range(model_out_blocks - 1)]
-        blocks.append(_conv_block(c, oc, model_ksize, pad1, pad2, None, None))
-        self.out_net = nn.Sequential(*blocks)
+        if model_unet:       # feed_forward.py:99-100,189-204: one or two output channels, whatever model_discrete says
+            oc = 2 if model_uncert else 1
+            self.out_net = _UNetTail(c, oc)
+        else:
+            blocks = [_conv_block(c, c, model_ksize, pad1, pad2, bn, model_batchnorm_momentum)
+                      for _ in range(model_out_blocks - 1)]
+            blocks.append(_conv_block(c, oc, model_ksize, pad1, pad2, None, None))
+            self.out_net = nn.Sequential(*blocks)
         self.out_chs = oc
+        self.unet = bool(model_unet)
 
-        self._native_ok = (model_ksize == 2 and not model_cross and bn and model_chs % 2 == 0
-                           and (4 * model_chs) % 8 == 0 and 4 * model_chs <= 288 and oc <= 128)
+        self._native_ok = (not model_unet and model_ksize == 2 and not model_cross and bn and model_chs % 2 == 0
+                           and (4 * model_chs) % 8 == 0 and 4 * model_chs <= 288 and oc <= 288)
         self._trunk = (Trunk(model_chs, model_in_blocks, model_out_blocks, model_views, oc,
                              model_batchnorm_momentum) if self._native_ok else None)
         self._param_names = [n for n, _ in self.named_parameters()]

@@ -94,6 +94,30 @@ def synth_state(spec, seed=0, trained_like=True):
     return out
 
 
+def formula_state(shapes, seed=0):
+    """name -> numpy array for ANY module tree, from its (name, shape) list alone: each tensor is drawn from its own
+    RandomState(crc32(name) ^ seed), so the values do not depend on construction or iteration order.  Used for the
+    flag combinations param_spec does not describe (e.g. --model_unet)."""
+    import zlib
+    out = {}
+    for name, shape in shapes:
+        rs = np.random.RandomState((zlib.crc32(name.encode()) ^ seed) & 0x7FFFFFFF)
+        shape = tuple(shape)
+        if name.endswith('num_batches_tracked'):
+            out[name] = np.array(0, dtype=np.int64)
+        elif name.endswith('running_var'):
+            out[name] = rs.uniform(0.05, 0.3, size=shape).astype(np.float32)
+        elif name.endswith('running_mean'):
+            out[name] = rs.uniform(-0.1, 0.1, size=shape).astype(np.float32)
+        elif len(shape) == 1:                 # bias or BatchNorm affine
+            out[name] = rs.uniform(0.5, 1.5, size=shape).astype(np.float32) if 'weight' in name \
+                else rs.uniform(-0.1, 0.1, size=shape).astype(np.float32)
+        else:
+            b = 1.0 / np.sqrt(np.prod(shape[1:]))
+            out[name] = rs.uniform(-b, b, size=shape).astype(np.float32)
+    return out
+
+
 def synth_inputs(batch, ps, views=9, seed=0, ps_w=None):
     """Four EPI stacks U[0,1) of shape (B, views, 3, ps, ps_w), gt in [-2, 2),
     and an int32 loss mask (all ones; the train step applies the 11-px margin,

@@ -54,6 +54,7 @@ class GradBuckets:
             self.ranges[key] = (min(lo, o), max(hi, o + n))
         self.pending = []
         self.done = set()
+        self.wait_events = None      # bench.py: a list that receives (start, end) HIP events around each step's waits
 
     def ready(self, flat_grad, key):
         if key in self.done or key not in self.ranges:
@@ -65,8 +66,15 @@ class GradBuckets:
     def finish(self, flat_grad):
         for key in self.ranges:
             self.ready(flat_grad, key)
+        timed = self.wait_events is not None and flat_grad.is_cuda
+        if timed:       # how long the compute stream stands behind the collectives once backward is through
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self.pending:
             w.wait()
+        if timed:
+            e1.record()
+            self.wait_events.append((e0, e1))
         self.pending, self.done = [], set()
 
 

@@ -524,7 +524,34 @@ def g10_pfm_and_f64():
         print('G10 f64', variant, float(loss))
 
 
+def g10_unet():
+    """--model_unet (reference feed_forward.py:189-204, unet.py): outputs only, weights by synth.formula_state"""
+    kw = dict(TINY_KW, model_unet=True, model_uncert=True)
+    model = RefFeedForward(**kw)
+    state = synth.formula_state([(k, v.shape) for k, v in model.state_dict().items()], seed=3)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    stacks, gt, mask = synth.synth_inputs(2, 32, seed=9)
+    rec = {'keys': np.array(list(model.state_dict().keys()))}
+    model.train()
+    out = model(*[torch.from_numpy(s) for s in stacks])
+    loss = ref_loss.ImprovedUncertaintyL1Loss()(out, torch.from_numpy(gt), train_mask(mask), None)
+    loss.backward()
+    rec['train_mean'], rec['train_logvar'] = out['mean'].detach().numpy(), out['logvar'].detach().numpy()
+    rec['loss'] = loss.detach().numpy()
+    rec['grad/out_net.last.weight'] = model.out_net.last.weight.grad.numpy().copy()
+    rec['grad/in_net_hv.0.0.weight'] = model.in_net_hv[0][0].weight.grad.numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        out = model(*[torch.from_numpy(s) for s in stacks])
+    rec['eval_mean'], rec['eval_logvar'] = out['mean'].numpy(), out['logvar'].numpy()
+    np.savez_compressed(os.path.join(HERE, 'g10_unet.npz'), **rec)
+    print('G10 unet', float(loss), len(rec['keys']), 'keys')
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'g10u':
+        g10_unet()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g10':
         g10_pfm_and_f64()
         sys.exit(0)
@@ -545,6 +572,7 @@ if __name__ == '__main__':
     g7_patch_pipeline()
     g8_extras()
     g10_pfm_and_f64()
+    g10_unet()
     sizes = {f: os.path.getsize(os.path.join(HERE, f)) for f in sorted(os.listdir(HERE))
              if f.endswith('.npz')}
     print(sizes)

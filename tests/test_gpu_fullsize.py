@@ -155,3 +155,69 @@ def test_fused_batchnorm_statistics_bs512_vs_float64(C):
     torch.testing.assert_close(c[3 * C:].double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-6, atol=0)
     torch.testing.assert_close(rv.double(), var * n / (n - 1), rtol=2e-6, atol=0)      # momentum 1: the unbiased batch variance
     assert torch.equal(z.absmax, geo.amax_of(z, cs))
+
+
+def test_upr_train_forward_and_loss_bs512_vs_stock_torch_ops():
+    """BASELINE.json configs[2] (UPR, bs=512) in TRAIN mode: both head channels, the uncertainty loss and the running
+    statistics against the stock torch ops on the same inputs (the BASE / DPP twin of this test is above)."""
+    from mmlf_amd import loss
+    kw = dict(BASE_KW, model_uncert=True)
+    stacks, gt = _inputs(512, 5)
+    mask = (torch.ones((512, 96, 96), dtype=torch.int32) * loss.create_mask_margin((512, 96, 96), 11)).to('cuda:0')
+    res = {}
+    for path in ('native', 'torch'):
+        m = _model(kw, seed=21)
+        m.train()
+        if path == 'torch':
+            m._native_ok = False
+        with torch.no_grad():
+            out = m(*stacks)
+            l = loss.ImprovedUncertaintyL1Loss()(out, gt, mask, None)
+        res[path] = (out['mean'].cpu(), out['logvar'].cpu(), float(l), out['posterior'][::64, ::9].cpu(),
+                     {k: v.cpu() for k, v in m.state_dict().items() if 'running' in k})
+        del m, out
+        torch.cuda.empty_cache()
+    a, b = res['native'], res['torch']
+    assert float((a[0] - b[0]).abs().mean()) <= DEPTH_MAE_TOL
+    assert float((a[1] - b[1]).abs().mean()) <= DEPTH_MAE_TOL
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-4)
+    torch.testing.assert_close(a[3], b[3], rtol=5e-3, atol=1e-6)
+    for k in b[4]:
+        torch.testing.assert_close(a[4][k], b[4][k], rtol=2e-4, atol=2e-6, msg=k)
+
+
+@pytest.mark.parametrize('mode', ['f16x3', 'f32'])
+def test_ensamble_512_batched_members_equal_chunked_members(mode, monkeypatch):
+    """BASELINE.json configs[4]: the 70 members of one 512x512 scene as ONE batch (what bench.py times) against the
+    same members run eight at a time (reference ensamble.py:58-101 runs them one by one).  Eval-mode BatchNorm is a
+    per-channel affine map, so batching is exact in exact arithmetic.  On the exact-f32 MFMA path every output is one
+    fixed-order fma chain whatever tile it lands in: bit for bit.  On the default f16 split the operand scale of a
+    32-position wave depends on where the wave's boundaries fall in the flat batch (a member is 514*514 positions: not a
+    multiple of 32), so the two runs may round differently -- at float32 rounding level, asserted here."""
+    from mmlf_amd import engine
+    from mmlf_amd.ensamble import Ensamble
+    monkeypatch.setattr(engine, 'CONV_MODE', mode)
+    m = _model(dict(BASE_KW, model_uncert=True), seed=21)
+    m.eval()
+    ens = Ensamble(m, -3.5, 3.5, 0.1).eval()
+    gen = torch.Generator(device='cuda:0').manual_seed(9)
+    stacks = [torch.rand((1, 9, 3, 512, 512), device='cuda:0', generator=gen) for _ in range(4)]
+    with torch.no_grad():
+        full = ens(*stacks)
+        full = {k: v.clone() for k, v in full.items()}
+        torch.cuda.empty_cache()
+        per_member = 514 * 514 * 4 * 70 * 4
+        ens.member_budget_bytes = 8 * per_member + 1
+        part = ens(*stacks)
+    assert full['means'].shape == (70, 1, 512, 512) and torch.isfinite(full['mean']).all()
+    if mode == 'f32':
+        for k in ('means', 'logvars', 'mean', 'logvar', 'posterior'):
+            assert torch.equal(full[k], part[k]), k
+    else:
+        for k in ('means', 'logvars'):
+            d = (full[k] - part[k]).abs()
+            assert float(d.mean()) <= 2e-6 and float(d.max()) <= 2e-4, (k, float(d.mean()), float(d.max()))
+        # the fused outputs pick the member of least logvar per pixel: identical wherever the choice is not a near-tie
+        same = (full['mean'] == part['mean']).float().mean()
+        assert float(same) >= 0.98, float(same)
+        torch.testing.assert_close(full['posterior'], part['posterior'], rtol=2e-3, atol=1e-6)

@@ -252,23 +252,26 @@ def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
     assert (g[:, 0] == 0).all() and (g[:, -1] == 0).all() and (g[:, :, 0] == 0).all() and (g[:, :, -1] == 0).all()
 
 
-def test_pack_unpack_roundtrip():
+@pytest.mark.parametrize('C,cs,W', [(27, 32, 12), (108, 112, 12), (132, 136, 12),     # 132 = DPP head at 11 views
+                                    (280, 280, 140), (288, 288, 5)])
+def test_pack_unpack_roundtrip(C, cs, W):
     from mmlf_amd import engine, _lib
     from mmlf_amd._lib import call, ptr
     dev = _dev()
     rs = np.random.RandomState(0)
-    B, C, H, W = 2, 27, 7, 12
+    B, H = 2, 7
     geo = engine.Geometry(B, H, W)
     x = rs.uniform(-1, 1, (B, C, H, W)).astype(np.float32)
-    g = torch.full((geo.alloc * 32,), float('nan'), device=dev)
-    g[geo.NQ * 32:] = 0
+    xd = torch.from_numpy(x).to(dev)
+    g = torch.full((geo.alloc * cs,), float('nan'), device=dev)
+    g[geo.NQ * cs:] = 0
     amax = torch.zeros(geo.amax_n, device=dev)
-    call('mmlf_pack_nchw', ptr(torch.from_numpy(x).to(dev)), C, ptr(g), 32, B, H, W, ptr(amax), _lib.stream_ptr())
+    call('mmlf_pack_nchw', ptr(xd), C, ptr(g), cs, B, H, W, ptr(amax), _lib.stream_ptr())
     assert float(amax[0]) == float(np.abs(x).max())
-    assert torch.equal(amax, geo.amax_of(g, 32))
-    np.testing.assert_array_equal(g.cpu().numpy(), grid_from_nchw(x, 32, geo))
+    assert torch.equal(amax, geo.amax_of(g, cs))
+    np.testing.assert_array_equal(g.cpu().numpy(), grid_from_nchw(x, cs, geo))
     back = torch.empty((B, C, H, W), device=dev)
-    call('mmlf_unpack_nchw', ptr(g), 32, ptr(back), C, B, H, W, _lib.stream_ptr())
+    call('mmlf_unpack_nchw', ptr(g), cs, ptr(back), C, B, H, W, _lib.stream_ptr())
     np.testing.assert_array_equal(back.cpu().numpy(), x)
 
 

@@ -146,6 +146,76 @@ def test_g2_full_size_train_step_vs_reference(variant):
             np.testing.assert_allclose(v.cpu().numpy(), g[f'post/{k}'], rtol=5e-5, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize('variant', ['base', 'upr'])
+def test_g2_train_gradients_against_the_float64_reference(variant):
+    """How far may a float32 implementation's gradients be from the truth?  tests/golden/g10_full_*_f64.npz is the
+    reference module run in float64 on the G2 train step; g2_full_*.npz its own float32 run.  Per parameter tensor the
+    HIP path's distance to the float64 gradients must not exceed 1.5 x the reference's own float32 distance (2.5 x for
+    tensors with fewer than 300 sampled elements, whose ratio is a noisy statistic) -- this replaces a blanket
+    tolerance with the reference's own conditioning, tensor by tensor -- and the median ratio must stay below 1.15."""
+    from mmlf_amd.loss import create_mask_margin
+    g32 = load_golden(f'g2_full_{variant}.npz')
+    g64 = load_golden(f'g10_full_{variant}_f64.npz')
+    kw = dict(BASE_KW, **VARIANTS[variant])
+    dev = _dev()
+    m = _model(kw, synth.synth_state(synth.param_spec(**kw), seed=21))
+    stacks, gt, mask = synth.synth_inputs(2, 96, seed=8)
+    mask = torch.from_numpy(mask).int() * create_mask_margin(mask.shape, 11)
+    m.train()
+    out = m(*[torch.from_numpy(s).to(dev) for s in stacks])
+    loss = _loss_fn(variant)(out, torch.from_numpy(gt).to(dev), mask.to(dev))
+    loss.backward()
+    # forward: depth against float64, no farther than the reference's float32 run x 1.5
+    e_hip = np.abs(out['mean'].detach().cpu().numpy().astype(np.float64) - g64['train_mean']).mean()
+    e_ref = np.abs(g32['train_mean'].astype(np.float64) - g64['train_mean']).mean()
+    assert e_hip <= 1.5 * e_ref + 1e-7, (e_hip, e_ref)
+    assert abs(loss.item() - float(g64['loss'])) <= 1.5 * abs(float(g32['loss']) - float(g64['loss'])) + 2e-6
+    ratios, gnorm = [], max(np.linalg.norm(g64[k]) for k in g64 if k.startswith('grad_s/'))
+    for n, p in m.named_parameters():
+        ref64 = g64[f'grad_s/{n}']
+        got = p.grad.cpu().numpy().astype(np.float64)
+        got = got.reshape(-1)[::97] if got.size > 4096 else got
+        ref32 = g32[f'grad_s/{n}'].astype(np.float64)
+        d_hip, d_ref = np.linalg.norm(got - ref64), np.linalg.norm(ref32 - ref64)
+        if n.endswith('.2.bias') and '.7.' not in n:
+            # a conv bias in front of BatchNorm: its true gradient is exactly 0 (float64: ~1e-17); both float32 runs hold noise
+            assert np.linalg.norm(ref64) <= 1e-9 * gnorm and d_hip <= 3.0 * d_ref + 1e-6 * gnorm, (n, d_hip, d_ref)
+            continue
+        lim = 1.5 if ref64.size >= 300 else 2.5
+        assert d_hip <= lim * d_ref + 1e-7 * gnorm, (n, d_hip / max(d_ref, 1e-30), d_hip / np.linalg.norm(ref64))
+        ratios.append(d_hip / max(d_ref, 1e-30))
+    assert np.median(ratios) <= 1.15, np.median(ratios)
+
+
+def test_dpp_with_eleven_views_runs_natively():
+    """--model_views 11 gives the DPP head 4*11*3 = 132 channels (channel stride 136): forward, the NCHW pack of its
+    gradient (a transpose tile that must not depend on the channel count) and backward against the stock torch ops"""
+    from mmlf_amd import dl, loss
+    kw = dict(TINY_KW, model_views=11, model_discrete=True)
+    state = synth.synth_state(synth.param_spec(**kw), seed=6)
+    stacks, gt, mask = synth.synth_inputs(2, 16, views=11, seed=6)
+    dev = _dev()
+    t = [torch.from_numpy(s).to(dev) for s in stacks]
+    res = {}
+    for path in ('native', 'torch'):
+        m = _model(kw, state)
+        assert m._native_ok and m.steps == 132
+        m.train()
+        if path == 'torch':
+            m._native_ok = False
+        out = m(*t)
+        l = loss.MaskedCrossEntropy()(out, dl.reg_to_class(torch.from_numpy(gt).to(dev), -3.5, 3.5, 132),
+                                      torch.from_numpy(mask).to(dev))
+        l.backward()
+        res[path] = (out['scores'].detach().cpu(), float(l), {n: p.grad.cpu() for n, p in m.named_parameters()})
+    a, b = res['native'], res['torch']
+    torch.testing.assert_close(a[0], b[0], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-5)
+    floor = 1e-4 * max(float(g.norm()) for g in b[2].values())
+    for n, ref in b[2].items():
+        assert float((a[2][n] - ref).norm()) <= 2e-3 * float(ref.norm()) + floor, n
+
+
 def test_full_size_vs_oracle_other_seed(oracle):
     """Same check against the CPU oracle itself on inputs no golden covers (B=3, 40x56 patch)."""
     kw = dict(BASE_KW, model_uncert=True)

@@ -194,3 +194,210 @@ def test_wgrad_patches_of_very_different_magnitude(cin, cout):
         assert err['f16x3'][0] <= 1.25 * err['f32'][0], (g_expo, err)
         assert err['f16x3'][1] <= 2.0 * err['f32'][1], (g_expo, err)
         assert err['f16x3'][2] <= 2.0 * err['f32'][2] + 1e-8, (g_expo, err)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# within-row outliers: the documented limit of the f16 split.  An element is split with the
+# scale of its WAVE (the maximum M of the 2-3 grid rows the wave's taps read): it keeps 22 bits while |a| >= M 2^-18,
+# below that the `lo` half runs into f16's subnormals and the absolute error of the split is at most M 2^-39
+# (half a subnormal step 2^-24 after scaling M to [2^14, 2^15)).  Stated as a bound per product:
+#       |err(a * b)| <= |b| * max(|a| 2^-22, M 2^-39)          (+ float32 accumulation, as in the exact-f32 kernel)
+# ---------------------------------------------------------------------------------------------------------------
+def _row_scale_max(x, pad):
+    """per output position: an upper bound of the maximum its wave is scaled by -- max |x| over the grid rows
+    row-2 .. row+2 around the output's row (a wave of 32 positions spans at most two rows at pitch >= 32, its
+    taps one more)"""
+    B, C, H, W = x.shape
+    rowmax = np.abs(x).max(axis=(1, 3))                       # (B, H) image rows
+    oh = H + 1 if pad else H - 1
+    out = np.zeros((B, oh))
+    for y in range(oh):                                       # output row y reads image rows y-pad, y-pad+1
+        lo, hi = max(0, y - pad - 2), min(H, y - pad + 4)
+        out[:, y] = rowmax[:, lo:hi].max(axis=1)
+    return out
+
+
+@pytest.mark.parametrize('cin,cout', [(280, 280), (70, 70)])
+@pytest.mark.parametrize('pad', [1, 0])
+@pytest.mark.parametrize('dgrad', [False, True])
+def test_conv_outlier_inside_a_row_meets_the_stated_bound(cin, cout, pad, dgrad):
+    """one element 2^20 (and one 2^30) above everything else in its grid row.  Per element class:
+    (i) outputs that read the outlier: float32-level error relative to their own sum |a*b|;
+    (ii) outputs of the rows around it that do not: the bound above (their scale is the outlier's);
+    (iii) every other output: float32-level error, as if the outlier were not there."""
+    from mmlf_amd import engine
+    rs = np.random.RandomState(17 * cin + 2 * pad + dgrad)
+    B, H, W = 2, 33, 37
+    geo = engine.Geometry(B, H, W)
+    K, N = (cout, cin) if dgrad else (cin, cout)
+    w = rs.uniform(-0.06, 0.06, (cout, cin, 2, 2)).astype(np.float32)
+    if dgrad:     # x plays the output gradient of a pad-`pad` conv; its data gradient is a pad-(1 - pad) conv
+        ih, iw = (H + 1, W + 1) if pad else (H, W)
+        weff, peff = np.ascontiguousarray(w.transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]), 1 - pad
+    else:
+        ih, iw = (H, W) if pad else (H + 1, W + 1)
+        weff, peff = w, pad
+    x = rs.uniform(-1, 1, (B, K, ih, iw)).astype(np.float32)
+    spots = [(0, 3, 11, 20, 2.0 ** 20), (1, K - 1, 20, 5, 2.0 ** 30)]         # (patch, channel, row, column, factor)
+    for b, c, y, xx, f in spots:
+        x[b, c, y, xx] = np.float32(f)
+    ref, mag = conv_f64(x, weff, peff)
+    wabs = np.abs(weff).astype(np.float64).sum(axis=(1, 2, 3))                  # sum |w| per output channel
+    M = _row_scale_max(x, peff)                                                # (B, oh)
+    got = {m: run_conv(engine, m, geo, x, w, pad, H, W, dgrad=dgrad) for m in ('f32', 'f16x3')}
+    err = {m: np.abs(got[m] - ref) for m in got}
+    assert np.isfinite(got['f16x3']).all()
+    # the stated bound, every output: split error of each product + the float32 accumulation both kernels share
+    bound = mag * 2.0 ** -22 + wabs[None, :, None, None] * M[:, None, :, None] * 2.0 ** -39 + 4 * err['f32'] + mag * 2.0 ** -23
+    assert (err['f16x3'] <= bound).all(), float((err['f16x3'] / bound).max())
+    reads = np.zeros(ref.shape[0:1] + ref.shape[2:], bool)                     # (B, oh, ow): reads an outlier
+    near = np.zeros_like(reads)
+    for b, c, y, xx, f in spots:
+        oy, ox = y + peff, xx + peff                                           # outputs (oy-1..oy, ox-1..ox) read it
+        reads[b, max(0, oy - 1):oy + 1, max(0, ox - 1):ox + 1] = True
+        near[b, max(0, oy - 3):oy + 3, :] = True
+    near &= ~reads
+    far = ~(near | reads)
+    rel = {m: err[m] / mag for m in err}
+    cls = lambda m, sel: rel[m].transpose(0, 2, 3, 1)[sel]                      # (positions, channels)
+    assert cls('f16x3', reads).mean() <= 1.5 * cls('f32', reads).mean() + 1e-9        # (i)
+    assert cls('f16x3', far).mean() <= 1.25 * cls('f32', far).mean()                  # (iii)
+    assert cls('f16x3', far).max() <= 1.6 * cls('f32', far).max()
+    # (ii) is where the arithmetic is weaker than float32, by design: at 2^20 about 2^2, at 2^30 about 2^12 in the
+    # worst product; what the sum shows is far less (random signs over 4 K products) -- pin the order of magnitude
+    assert cls('f16x3', near).mean() <= 2.0 ** -14, cls('f16x3', near).mean()
+
+
+def test_conv_heavy_tailed_rows_stay_at_f32_accuracy():
+    """every row log-uniform over 24 binades (|x| = 2^-24 .. 1, random signs): the large elements carry the sums, the
+    small ones lose split bits that are below float32's own accumulation error -- error relative to sum |a*b| stays
+    at the exact-f32 kernel's level for every output row"""
+    from mmlf_amd import engine
+    rs = np.random.RandomState(23)
+    B, H, W, cin, cout = 2, 33, 37, 280, 280
+    geo = engine.Geometry(B, H, W)
+    x = (np.exp2(-24.0 * rs.uniform(size=(B, cin, H, W))) * rs.choice([-1.0, 1.0], size=(B, cin, H, W))).astype(np.float32)
+    w = rs.uniform(-0.06, 0.06, (cout, cin, 2, 2)).astype(np.float32)
+    ref, mag = conv_f64(x, w, 1)
+    rel = {m: np.abs(run_conv(engine, m, geo, x, w, 1, H, W) - ref) / mag for m in ('f32', 'f16x3')}
+    assert rel['f16x3'].mean() <= 1.25 * rel['f32'].mean(), (rel['f16x3'].mean(), rel['f32'].mean())
+    per_row = {m: rel[m].mean(axis=(1, 3)) for m in rel}
+    assert (per_row['f16x3'] <= 1.5 * per_row['f32']).all()
+    assert rel['f16x3'].max() <= 2.0 * rel['f32'].max()
+
+
+@pytest.mark.parametrize('cin,cout', [(280, 280), (70, 70)])
+@pytest.mark.parametrize('where', ['activation', 'gradient'])
+def test_wgrad_outlier_inside_a_row(cin, cout, where):
+    """one activation (or one output gradient) 2^20 above the rest of its tensor: the chunk that holds it is staged with
+    the outlier's scale, every other chunk moves its headroom to the other operand (wgrad_chunk_scales_kernel) -- the
+    weight gradient keeps float32-level error relative to sum |in * g|, for the outlier's channel and for all others"""
+    from mmlf_amd import engine, _lib
+    dev = _dev()
+    rs = np.random.RandomState(cin + len(where))
+    B, H, W = 3, 33, 37
+    geo = engine.Geometry(B, H, W)
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    x = rs.uniform(-1, 1, (B, cin, H, W)).astype(np.float32)
+    g = rs.normal(size=(B, cout, H + 1, W + 1)).astype(np.float32)
+    ch = 5
+    if where == 'activation':
+        x[1, ch, 17, 9] = np.float32(2.0 ** 20)
+    else:
+        g[1, ch, 17, 9] = np.float32(2.0 ** 20)
+    xp = np.zeros((B, cin, H + 2, W + 2), np.float64)
+    xp[:, :, 1:-1, 1:-1] = x
+    ref = np.zeros((cout, cin, 2, 2), np.float64)
+    mag = np.zeros_like(ref)
+    for dy in range(2):
+        for dx in range(2):
+            patch = xp[:, :, dy:dy + H + 1, dx:dx + W + 1]
+            ref[:, :, dy, dx] = np.einsum('bohw,bchw->oc', g.astype(np.float64), patch)
+            mag[:, :, dy, dx] = np.einsum('bohw,bchw->oc', np.abs(g).astype(np.float64), np.abs(patch))
+    xg = torch.from_numpy(grid_from_nchw(x, cs_in, geo, offset=1)).to(dev)
+    gg = torch.from_numpy(grid_from_nchw(g, cs_out, geo, offset=0)).to(dev)
+    ws = torch.empty(int(_lib.load().mmlf_wgrad_workspace_floats(cin, cout, B, H, W)), device=dev)
+    rel, gbs = {}, {}
+    for mode in ('f32', 'f16x3'):
+        keep, engine.CONV_MODE = engine.CONV_MODE, mode
+        try:
+            gw, gb = torch.zeros((cout, cin, 2, 2), device=dev), torch.zeros(cout, device=dev)
+            engine.wgrad(geo, xg, cs_in, cin, gg, cs_out, cout, 0, gw, gb, 0, ws)
+        finally:
+            engine.CONV_MODE = keep
+        assert torch.isfinite(gw).all() and torch.isfinite(gb).all()
+        rel[mode] = np.abs(gw.cpu().numpy().astype(np.float64) - ref) / mag
+        gbs[mode] = np.abs(gb.cpu().numpy() - g.astype(np.float64).sum(axis=(0, 2, 3))) / np.abs(g).astype(np.float64).sum(axis=(0, 2, 3))
+    hot = rel['f16x3'][:, ch] if where == 'activation' else rel['f16x3'][ch]
+    hot32 = rel['f32'][:, ch] if where == 'activation' else rel['f32'][ch]
+    assert rel['f16x3'].mean() <= 1.25 * rel['f32'].mean(), (rel['f16x3'].mean(), rel['f32'].mean())
+    assert rel['f16x3'].max() <= 2.0 * rel['f32'].max()
+    assert hot.mean() <= 1.5 * hot32.mean() + 1e-9
+    assert gbs['f16x3'].max() <= 2.0 * gbs['f32'].max() + 1e-8
+
+
+def test_values_only_invalid_positions_read_cannot_poison_a_wave():
+    """The wave scale comes from the rows VALID outputs read.  At a small pitch a wave of 32 positions reaches from a
+    patch's last valid rows over its invalid bottom rows, whose taps read the NEXT patch's first row: a value there
+    that overflows f16 under this wave's scale puts inf / NaN into the accumulators of the invalid positions.  They
+    must stay there: outputs, fused BatchNorm sums, row maxima and ReLU mask bits must be finite and equal to what the
+    exact-f32 path / a direct evaluation gives."""
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    dev = _dev()
+    rs = np.random.RandomState(4)
+    B, H, W, cin, cout = 4, 6, 8, 70, 70              # pitch 10: a wave spans more than three grid rows
+    geo = engine.Geometry(B, H, W)
+    cs = engine.cs_of(cin)
+    x = rs.uniform(-1, 1, (B, cin, H + 1, W + 1)).astype(np.float32)         # input of a pad-0 conv: extent (H+1, W+1) at (0, 0)
+    x[1, :, 0, :] = np.float32(1e15) * rs.uniform(0.5, 1.0, (cin, W + 1)).astype(np.float32)   # patch 1, first row
+    x[3, 7, 0, 2] = np.float32(-3e14)
+    w = rs.uniform(-0.06, 0.06, (cout, cin, 2, 2)).astype(np.float32)
+    bias = rs.uniform(-0.5, 0.5, cout).astype(np.float32)
+    ref, mag = conv_f64(x, w, 0)
+    ref += bias[None, :, None, None]
+    xg = torch.from_numpy(grid_from_nchw(x, cs, geo, offset=0)).to(dev)
+    wd, bd = torch.from_numpy(w).to(dev), torch.from_numpy(bias).to(dev)
+    keep, engine.CONV_MODE = engine.CONV_MODE, 'f16x3'
+    try:
+        pk = engine.pack_filter(wd, 0, False)
+        nblk = int(_lib.load().mmlf_conv2x2_blocks(cout, B, H, W))
+        for relu in (False, True):
+            z = geo.buf(cs, dev)
+            partial = torch.full((nblk * 2 * cout + 8,), float('nan'), dtype=torch.float64, device=dev)
+            mask = torch.zeros_like(geo.relu_mask(dev)) if relu else None
+            engine.conv(geo, xg, cs, cin, pk, bd, cout, z, cs, geo.P + 1, H, W, relu,
+                        bn_partial=None if relu else partial, mask_out=mask)
+            torch.cuda.synchronize()
+            zc = z.cpu().numpy()
+            assert np.isfinite(zc).all()
+            got, grid = nchw_from_grid(zc, cs, cout, geo, H, W, 1)
+            want = np.maximum(ref, 0.0) if relu else ref
+            assert (np.abs(got - want) <= 4e-7 * (mag + np.abs(bias)[None, :, None, None])).all()
+            # nothing outside the valid extent
+            border = grid.copy()
+            border[:, 1:1 + H, 1:1 + W, :] = 0
+            assert not border.any()
+            # row maxima are the stored tensor's true maxima
+            assert torch.isfinite(z.absmax).all()
+            true = geo.amax_of(z, cs)
+            assert float(z.absmax[0]) == float(true[0]) and bool((z.absmax >= true).all())
+            if relu:                 # mask bits == (stored output > 0): a data gradient masked by them equals one masked by z
+                gy = torch.from_numpy(grid_from_nchw(rs.normal(size=(B, cout, H + 1, W + 1)).astype(np.float32), cs, geo,
+                                                     offset=0)).to(dev)
+                pkd = engine.pack_filter(wd, 0, True)
+                d1, d2 = geo.buf(cs, dev), geo.buf(cs, dev)
+                engine.conv(geo, gy, cs, cout, pkd, None, cin, d1, cs, geo.P + 1, H, W, False, mask_in=mask)
+                engine.conv(geo, gy, cs, cout, pkd, None, cin, d2, cs, geo.P + 1, H, W, False, ref=z, cs_ref=cs)
+                assert torch.isfinite(d1).all() and torch.equal(d1, d2)
+            else:                    # fused statistics = sums over the stored (finite) output
+                c = torch.empty(4 * cout, device=dev)
+                rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+                gamma, beta = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+                call('mmlf_bn_stats_finalize', ptr(partial), nblk, cout, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1.0, 1e-5,
+                     ptr(c[2 * cout:]), ptr(c[3 * cout:]), ptr(c), ptr(c[cout:]), B, H, W, _lib.stream_ptr())
+                mean = got.astype(np.float64).mean(axis=(0, 2, 3))
+                assert torch.isfinite(c).all()
+                np.testing.assert_allclose(c[2 * cout:3 * cout].cpu().numpy(), mean, rtol=1e-5, atol=1e-3 * np.abs(mean).max())
+    finally:
+        engine.CONV_MODE = keep

@@ -60,11 +60,42 @@ def test_config0_base_full_size_cpu_forward():
     assert np.abs(out['mean'].numpy() - g['eval_mean']).mean() < 1e-5
 
 
-def test_unsupported_flags():
-    with pytest.raises(NotImplementedError):
-        FeedForward(**dict(TINY_KW, model_unet=True))
+def test_non_default_flags_take_the_stock_torch_path():
     m = FeedForward(**dict(TINY_KW, model_cross=True))
-    assert not hasattr(m, 'in_net_id') and m.steps == 54
+    assert not hasattr(m, 'in_net_id') and m.steps == 54 and not m._native_ok
+
+
+@pytest.mark.parametrize('dev', ['cpu', pytest.param('cuda', marks=pytest.mark.gpu)])
+def test_model_unet_fallback_matches_reference_golden(dev):
+    """--model_unet stays accepted and runs stock torch ops (reference feed_forward.py:99-100,
+    189-204 + unet.py); same state_dict keys, same outputs, loss and gradients as the reference module."""
+    from mmlf_amd import loss as loss_mod
+    g = load_golden('g10_unet.npz')
+    kw = dict(TINY_KW, model_unet=True, model_uncert=True)
+    model = FeedForward(**kw)
+    assert list(model.state_dict().keys()) == list(g['keys']) and not model._native_ok
+    _load(model, synth.formula_state([(k, v.shape) for k, v in model.state_dict().items()], seed=3))
+    model.to(dev)
+    stacks, gt, mask = synth.synth_inputs(2, 32, seed=9)
+    t = [torch.from_numpy(s).to(dev) for s in stacks]
+    tol = dict(rtol=1e-5, atol=1e-6) if dev == 'cpu' else dict(rtol=2e-3, atol=2e-4)   # MIOpen vs mkldnn summation order
+    model.train()
+    out = model(*t)
+    m = torch.from_numpy(mask).int() * loss_mod.create_mask_margin(mask.shape, 11)
+    val = loss_mod.ImprovedUncertaintyL1Loss()(out, torch.from_numpy(gt).to(dev), m.to(dev), None)
+    val.backward()
+    np.testing.assert_allclose(out['mean'].detach().cpu().numpy(), g['train_mean'], **tol)
+    np.testing.assert_allclose(out['logvar'].detach().cpu().numpy(), g['train_logvar'], **tol)
+    np.testing.assert_allclose(val.item(), g['loss'], rtol=tol['rtol'])
+    for name in ('out_net.last.weight', 'in_net_hv.0.0.weight'):
+        got = dict(model.named_parameters())[name].grad.cpu().numpy()
+        ref = g[f'grad/{name}']
+        assert np.linalg.norm(got - ref) <= (1e-4 if dev == 'cpu' else 2e-2) * np.linalg.norm(ref), name
+    model.eval()
+    with torch.no_grad():
+        out = model(*t)
+    np.testing.assert_allclose(out['mean'].cpu().numpy(), g['eval_mean'], **tol)
+    np.testing.assert_allclose(out['logvar'].cpu().numpy(), g['eval_logvar'], **tol)
 
 
 def test_c_abi_exports_every_declared_symbol():
@@ -77,6 +108,6 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mmlf_abi_version() == 3
+    assert lib.mmlf_abi_version() == _lib.ABI_VERSION
     lib.mmlf_grid_alloc_positions.restype = ctypes.c_int64
     assert lib.mmlf_grid_alloc_positions(2, 96, 96) >= 2 * 98 * 98 + 99

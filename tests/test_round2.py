@@ -226,3 +226,53 @@ def test_dataparallel_replicas_on_the_native_path():
     for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
         scale = max(float(q.grad.abs().max()), 1e-6)
         assert float((p.grad - q.grad).abs().max()) <= 2e-4 * scale + 1e-7, n
+
+
+@pytest.mark.gpu
+def test_dataparallel_forwards_do_not_accumulate_workspaces():
+    """DataParallel.parallel_apply starts fresh threads on every forward; the engine's per-thread workspaces
+    (partial-sum buffer, side stream, weight-gradient scratch) must die with them: 50 forward/backward passes leave
+    the caching allocator where the first few put it."""
+    import gc
+    import threading
+    from mmlf_amd import engine
+    kw = dict(TINY_KW, model_uncert=True)
+    state = synth.synth_state(synth.param_spec(**kw), seed=5)
+    stacks, gt, mask = synth.synth_inputs(4, 16, seed=3)
+    dev = 'cuda:0'
+    data = [torch.from_numpy(s).to(dev) for s in stacks]
+    tgt, tmask = torch.from_numpy(gt).to(dev), torch.from_numpy(mask).to(dev)
+    m = _fresh(kw, state, dev)
+    try:
+        dp = torch.nn.DataParallel(m, device_ids=[0, 0])
+        dp.train()
+        dp(*data)
+    except (RuntimeError, AssertionError, ValueError) as e:
+        pytest.skip(f'DataParallel(device_ids=[0, 0]) not possible here: {e}')
+    seen = set()
+    orig = engine._Workspace.__init__
+
+    def counting(self, device):
+        seen.add(threading.get_ident())
+        orig(self, device)
+
+    engine._Workspace.__init__ = counting
+    try:
+        def one():
+            out = dp(*data)
+            loss.ImprovedUncertaintyL1Loss()(out, tgt, tmask, None).backward()
+            m.zero_grad(set_to_none=True)
+
+        for _ in range(5):
+            one()
+        torch.cuda.synchronize(); gc.collect()
+        reserved, allocated = torch.cuda.memory_reserved(), torch.cuda.memory_allocated()
+        for _ in range(50):
+            one()
+        torch.cuda.synchronize(); gc.collect()
+    finally:
+        engine._Workspace.__init__ = orig
+    assert len(seen) >= 1                                   # workspaces were (re)created by worker threads
+    assert torch.cuda.memory_allocated() <= allocated + (1 << 20), (allocated, torch.cuda.memory_allocated())
+    assert torch.cuda.memory_reserved() <= reserved + (32 << 20), (reserved, torch.cuda.memory_reserved())
+    assert not hasattr(engine._Workspace, '_cache')         # no process-lifetime table of per-thread entries
