@@ -96,6 +96,19 @@ int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void *packed, co
 int64_t mmlf_amax_entries(int B, int H, int W);
 int64_t mmlf_packed_filter_h2_bytes(int K, int N);
 int mmlf_pack_filter_h2(const float *w_oihw, void *packed, int Cout, int Cin, int variant, int dgrad, void *stream);
+/* The same for MANY filters in one launch (a training step packs every filter of the net twice -- forward and data
+ * gradient -- from weights that Adam has just rewritten: 76 launches of ~6 us at the default hyper-parameters, which is
+ * 1 % of a 64-patch step).  `table` is a DEVICE array of n descriptors; its pointers stay owned by the caller.
+ * replaces: the same filter layout transforms inside nn.Conv2d (feed_forward.py:123,125), per optimisation step. */
+typedef struct mmlf_pack_desc {
+    const float *w_oihw;   /* OIHW master filter (Cout, Cin, 2, 2) */
+    void *packed;          /* mmlf_packed_filter_h2_bytes(K, N) bytes */
+    int32_t Cout, Cin, variant, dgrad;
+    int32_t col0;          /* first packed column of this filter in the launch: running sum of the filters' packed widths */
+    int32_t np;            /* packed width of this filter, = mmlf_packed_filter_h2_columns(N) */
+} mmlf_pack_desc;
+int mmlf_packed_filter_h2_columns(int N);
+int mmlf_pack_filters_h2(const mmlf_pack_desc *table, int n, int total_columns, void *stream);
 int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
                     float *out, int cs_out, int N_store, int out_shift, int vh, int vw,
                     int B, int H, int W, int relu, const float *relu_ref, int cs_ref,
@@ -198,6 +211,8 @@ int mmlf_unpack_nchw(const float *grid, int cs, float *nchw, int C, int B, int H
 /* zero the slack of a freshly allocated grid buffer: positions [0, P+1) and [B*G, mmlf_grid_alloc_positions),
  * and (amax nullable) the buffer's amax array */
 int mmlf_zero_slack(float *grid, int cs, int B, int H, int W, float *amax, void *stream);
+/* the same for up to four buffers of one (B, H, W) geometry in one launch (null grid pointers are skipped) */
+int mmlf_zero_slack4(float *const grid[4], const int cs[4], float *const amax[4], int B, int H, int W, void *stream);
 
 /* UPR head (feed_forward.py:292-302, laplacian :9-12): posterior[b,k,y,x] from output[:,0:2]. */
 int mmlf_head_upr(const float *output_nchw, const float *grid108, float *posterior, int steps,

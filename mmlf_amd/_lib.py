@@ -31,6 +31,8 @@ SIGNATURES = {
     'mmlf_packed_filter_h2_bytes': (_i64, [_i, _i]),
     'mmlf_amax_entries': (_i64, [_i, _i, _i]),
     'mmlf_pack_filter_h2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_packed_filter_h2_columns': (_i, [_i]),
+    'mmlf_pack_filters_h2': (_i, [_vp, _i, _i, _vp]),
     'mmlf_conv2x2_h2': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'mmlf_relu_mask_words': (_i64, [_i, _i, _i]),
     'mmlf_conv2x2_thin_workspace_floats': (_i64, [_i, _i, _i]),
@@ -49,6 +51,7 @@ SIGNATURES = {
     'mmlf_bn_bwd_apply': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'mmlf_pack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     'mmlf_zero_slack': (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    'mmlf_zero_slack4': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'mmlf_unpack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_head_upr': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_head_dpp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -63,7 +66,7 @@ SIGNATURES = {
     'mmlf_ensamble_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
-ABI_VERSION = 3          # include/mmlf_hip.h MMLF_ABI_VERSION: bumped whenever an entry point's arguments change
+ABI_VERSION = 4          # include/mmlf_hip.h MMLF_ABI_VERSION: bumped whenever an entry point's arguments change
 _lib = None
 
 

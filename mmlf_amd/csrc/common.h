@@ -65,9 +65,8 @@ static inline Grid make_grid(int B, int H, int W)
     return g;
 }
 
-// slack: taps reach P+1 past a tile; the split kernel's last DMA piece reads 64 positions more; a HALF tile's activation
-// window starts half a tile later and is as long as a full tile's
-static inline long long grid_alloc_positions(const Grid &g) { return g.NQpad + g.P + 8 + 64 + MMLF_TILE_MAX / 2; }
+// slack: taps reach P+1 past a tile; the split kernel's last DMA piece reads 64 positions more
+static inline long long grid_alloc_positions(const Grid &g) { return g.NQpad + g.P + 8 + 64; }
 
 // ---- max |x| bookkeeping of the f16-split arithmetic ("amax array" of a grid tensor) ----
 // [0] = max |x| over the whole tensor, [1 + r] = max |x| over grid row r = q / P (all channels).  Entries are

@@ -212,11 +212,11 @@ __device__ __forceinline__ void split2_pair_f16(float a, float b, float s, unsig
 // column n (= output channel of the launch).  Every column carries its own power-of-two scale (its max |w|
 // goes to [2^14, 2^15)), so an output channel whose weights are small as a whole keeps its 22 bits;
 // unscale[n] = 1 / scale[n] is what the convolution's epilogue multiplies column n by.
-__global__ __launch_bounds__(256) void pack_filter_h2_kernel(const float *__restrict__ w, unsigned short *__restrict__ out,
-                                                             int Cout, int Cin, int variant, int dgrad, int nchunk,
-                                                             int NP, float *__restrict__ unscale)
+__device__ __forceinline__ void pack_filter_h2_column(const float *__restrict__ w, unsigned short *__restrict__ out,
+                                                      int Cout, int Cin, int variant, int dgrad, int nchunk, int NP,
+                                                      float *__restrict__ unscale, int n, float *red)
 {
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
     auto at = [&](int k, int tap) -> size_t {      // OIHW index of (packed row k, column n, master tap)
         return dgrad ? ((size_t)k * Cin + n) * 4 + tap : ((size_t)n * Cin + k) * 4 + tap;
@@ -224,7 +224,6 @@ __global__ __launch_bounds__(256) void pack_filter_h2_kernel(const float *__rest
     float m = 0.f;
     if (n < N)
         for (int e = tid; e < 4 * K; e += 256) m = fmaxf(m, fabsf(w[at(e >> 2, e & 3)]));
-    __shared__ float red[4];
     m = mmlf_wave_max(m);
     if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
@@ -250,6 +249,31 @@ __global__ __launch_bounds__(256) void pack_filter_h2_kernel(const float *__rest
         *reinterpret_cast<uint4 *>(out + ((((size_t)c * 2 + 0) * 4 + t) * NP + n) * 8) = vh;
         *reinterpret_cast<uint4 *>(out + ((((size_t)c * 2 + 1) * 4 + t) * NP + n) * 8) = vl;
     }
+}
+
+__global__ __launch_bounds__(256) void pack_filter_h2_kernel(const float *__restrict__ w, unsigned short *__restrict__ out,
+                                                             int Cout, int Cin, int variant, int dgrad, int nchunk,
+                                                             int NP, float *__restrict__ unscale)
+{
+    __shared__ float red[4];
+    pack_filter_h2_column(w, out, Cout, Cin, variant, dgrad, nchunk, NP, unscale, blockIdx.x, red);
+}
+
+// many filters, one launch: workgroup b packs column b - col0 of the filter whose column range holds b
+__global__ __launch_bounds__(256) void pack_filters_h2_kernel(const mmlf_pack_desc *__restrict__ table, int n)
+{
+    __shared__ float red[4];
+    int lo = 0, hi = n - 1;                          // last descriptor with col0 <= blockIdx.x (wave-uniform search)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].col0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const mmlf_pack_desc d = table[lo];
+    const int K = d.dgrad ? d.Cout : d.Cin;
+    const int nchunk = (K + 7) / 8;
+    unsigned short *out = reinterpret_cast<unsigned short *>(d.packed);
+    float *tail = reinterpret_cast<float *>(reinterpret_cast<char *>(d.packed) + (size_t)nchunk * 8 * d.np * 16);
+    pack_filter_h2_column(d.w_oihw, out, d.Cout, d.Cin, d.variant, d.dgrad, nchunk, d.np, tail, (int)blockIdx.x - d.col0, red);
 }
 
 // split-precision filter packing: [chunk][plane(3)][tap(4)][NP][8 bf16], k = 8*chunk+j
@@ -327,7 +351,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
     // (same grid, same N, hence the same layout) reads its eight words with eight coalesced loads up front instead of
     // 8 x G scattered loads of the activations between its stores (a fifth of that launch)
     const bool use_bits = GEN ? a.relu_mask_in != nullptr : (EPI & EPI_BITS_IN) != 0;
-    const size_t mbase = ((size_t)(Q0 >> 5) + w) * 512 + (r16 + 16 * q4);      // global 32-position wave (Q0 is a multiple of 32)
+    const size_t mbase = ((size_t)(Q0 / MMLF_TILE) * 8 + w) * 512 + (r16 + 16 * q4);
     unsigned mw[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) mw[k] = use_bits ? a.relu_mask_in[mbase + 64 * k] : 0u;
@@ -475,19 +499,8 @@ __device__ __forceinline__ ConvArgs late_args()
 // are bound by memory concurrency, not by the matrix cores).  Layouts (masks, statistics, scales) are indexed by the
 // global 32-position group, so the two variants produce the same bytes.
 template <int G, int PL, int EPI = EPI_GENERIC, int NW = 8>
-__global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int nitems, int split_from)
+__global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
 {
-    // Work items: item t < split_from is the full tile t.  When the tiles do not fill the last round of the persistent
-    // grid (R = ntiles mod grid with 2R <= grid), each of its R tiles is cut into two HALF tiles for two workgroups:
-    // items split_from + 2k and + 2k + 1 are positions [0, TILE/2) and [TILE/2, TILE) of tile split_from + k, worked
-    // on by waves 0 .. NW/2 - 1 alone -- one wave per SIMD, which runs its chunk in little more than half the time two
-    // waves sharing the matrix pipe need -- while waves NW/2 .. only issue their share of the DMA pieces and keep
-    // the barriers.  The last round then costs ~0.55 of a round instead of 1 (10 -> 9.55 rounds at 64 patches per GPU).
-    // All layouts (ReLU mask words, statistics, scales, row maxima) are indexed by the global 32-position wave
-    // Q0 / 32 + w, so a half tile writes the same bytes as the full tile would have.
-#define X6_ITEM_Q0(t)                                                                                    \
-    ((t) < split_from ? (long long)(t) * TILE                                                            \
-                      : (long long)(split_from + (((t) - split_from) >> 1)) * TILE + (((t) - split_from) & 1) * (TILE / 2))
     constexpr int NP = G * 16;
     constexpr int TILE = 32 * NW;
     // pipeline buffers: two; the sixteen-wave variant has the LDS for a ring of MMLF_RING16, with the DMA of chunk
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
     const char *in0 = reinterpret_cast<const char *>(a.in);
     const char *wp_base = reinterpret_cast<const char *>(a.wp);
-    const size_t pos_bytes = (size_t)a.cs_in * 4;
+    const size_t tile_bytes = (size_t)TILE * a.cs_in * 4;
     // Piece ownership, fixed for the launch: of the chunk's pieces j = 0 .. a_pieces + N_B - 1 (activation
     // pieces first) wave w issues j = w, w+8, ...: nA activation pieces, then nB weight pieces that are
     // 8 KiB apart in both the packed filter and LDS.  The first half of them goes out in slot 0.
@@ -564,7 +577,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             const char *sb_;                                                                             \
             unsigned vo_, d_;                                                                            \
             if ((k) < nA) {                                                                              \
-                sb_ = in0 + (size_t)(tl) * pos_bytes + 32u * (c) + a_src[(k) < 3 ? (k) : 0];             \
+                sb_ = in0 + (size_t)(tl) * tile_bytes + 32u * (c) + a_src[(k) < 3 ? (k) : 0];            \
                 d_ = a_dst[(k) < 3 ? (k) : 0];                                                           \
                 vo_ = min(voff_a, (d_ & 1u) ? tail_lim : 0xffffffffu);                                   \
                 d_ &= ~1u;                                                                               \
@@ -608,10 +621,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     const int per_xcd = (int)gridDim.x >> 3;
     const int first_tile = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3)
                                                 : (int)blockIdx.x;
-    int tile = first_tile, c = 0;          // item / chunk being multiplied
-    int ntile = tile, nc = 0;              // item / chunk being fetched (one ahead)
-    if (tile >= nitems) return;
-    long long q0 = X6_ITEM_Q0(tile), nq0 = q0;   // first grid position of the two items
+    int tile = first_tile, c = 0;          // chunk being multiplied
+    int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
+    if (tile >= ntiles) return;
     // optional BatchNorm statistics of the output: per-wave double sums behind the two pipeline buffers
     double *stats_all = reinterpret_cast<double *>(lds + D * BUF_F4);        // [NW waves][NP][2]
     if (late_args().bn_partial)
@@ -619,16 +631,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     // f16 split: operand scales (powers of two) and what undoes them in the epilogue
     float scale_a = 1.f, unscale_a = 1.f, run_max = 0.f;
     if constexpr (PL == 2) {
-        scale_a = wave_operand_scale(wave_operand_amax_gather(late_args(), q0, w, lane));
+        scale_a = wave_operand_scale(wave_operand_amax_gather(late_args(), (long long)tile * TILE, w, lane));
         unscale_a = 1.f / scale_a;
     }
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) {
-        if (ntile < nitems) {
-            X6_DMA_SLOT(nq0, nc, d, 0);
-            X6_DMA_SLOT(nq0, nc, d, 1);
+        if (ntile < ntiles) {
+            X6_DMA_SLOT(ntile, nc, d, 0);
+            X6_DMA_SLOT(ntile, nc, d, 1);
         }
-        if (++nc == a.nchunk) { nc = 0; ntile += gridDim.x; nq0 = X6_ITEM_Q0(ntile); }
+        if (++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
     }
     X6_DMA_WAIT();
     __syncthreads();
@@ -649,23 +661,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                 bq[g0][pl] = (reinterpret_cast<const bf16x8 *>(lds + A_F4) + b_lane)[pl * 4 * NP + 16 * g0];
     }
 
-    while (tile < nitems) {
+    while (tile < ntiles) {
         // opaque to the optimiser: keeps the per-piece address terms derived from it from being hoisted out
         // of the persistent loop into (spilled) SGPRs; they are recomputed on the scalar unit instead
         asm volatile("" : "+s"(n_mine));
-        const bool more = ntile < nitems;
+        const bool more = ntile < ntiles;
         const int fb = buf == 0 ? D - 1 : buf - 1;             // the buffer multiplied last: free for chunk c + D - 1
-        if (tile >= split_from && w >= NW / 2) {
-            // half tile (always a workgroup's last item): this wave owns no positions of it.  It still issues its DMA
-            // pieces, waits for them and keeps the chunk's one barrier.
-            if (more) { X6_DMA_SLOT(nq0, nc, fb, 0); X6_DMA_SLOT(nq0, nc, fb, 1); }
-            if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; nq0 = X6_ITEM_Q0(ntile); }
-            X6_CHUNK_WAIT();
-            __syncthreads();
-            if (++c == a.nchunk) { c = 0; tile += gridDim.x; }
-            buf = buf + 1 == D ? 0 : buf + 1;
-            continue;
-        }
         const float4 *base = lds + buf * BUF_F4;
         const float4 *nbase = lds + (buf + 1 == D ? 0 : buf + 1) * BUF_F4;   // the next chunk's buffer
         // lane (r16, q4): row r16 of a 16-position block, tap q4 -> slot offset (q4&1) + (q4>>1)*seg_slot
@@ -730,9 +731,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             __builtin_amdgcn_sched_barrier(0);
             if (more) {   // both slots of a wave in one go, as early as the buffer is free; the two waves of a SIMD apart
                 if (w < NW / 2) {
-                    if (g == 0) { X6_DMA_SLOT(nq0, nc, fb, 0); X6_DMA_SLOT(nq0, nc, fb, 1); }
+                    if (g == 0) { X6_DMA_SLOT(ntile, nc, fb, 0); X6_DMA_SLOT(ntile, nc, fb, 1); }
                 } else {
-                    if (g == (PL == 2 && G >= 8 ? G / 8 : G / 4)) { X6_DMA_SLOT(nq0, nc, fb, 0); X6_DMA_SLOT(nq0, nc, fb, 1); }
+                    if (g == (PL == 2 && G >= 8 ? G / 8 : G / 4)) { X6_DMA_SLOT(ntile, nc, fb, 0); X6_DMA_SLOT(ntile, nc, fb, 1); }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
 #undef H2_TERM
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; nq0 = X6_ITEM_Q0(ntile); }
+        if (more && ++nc == a.nchunk) { nc = 0; ntile += gridDim.x; }
         // the next chunk's DMA pieces must have landed before the barrier; at a tile end wait for them
         // BEFORE the epilogue, so that its stores (same counter) stay in flight across the barrier
         if constexpr (!EARLY) X6_CHUNK_WAIT();
@@ -769,9 +770,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             const ConvArgs e = late_args(); // epilogue-only arguments: loaded here, dead again at the barrier
             float next_amax = 0.f;          // the next tile's row maxima: loads in flight during the epilogue
             if constexpr (PL == 2)
-                if (tile + (int)gridDim.x < nitems)
-                    next_amax = wave_operand_amax_gather(e, X6_ITEM_Q0(tile + (int)gridDim.x), w, lane);
-            conv_epilogue16<G, EPI>(e, acc, q0, w, r16, q4, unscale_a, run_max,
+                if (tile + (int)gridDim.x < ntiles)
+                    next_amax = wave_operand_amax_gather(e, (long long)(tile + gridDim.x) * TILE, w, lane);
+            conv_epilogue16<G, EPI>(e, acc, (long long)tile * TILE, w, r16, q4, unscale_a, run_max,
                                e.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -781,9 +782,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                     for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
             c = 0;
             tile += gridDim.x;
-            q0 = X6_ITEM_Q0(tile);
             if constexpr (PL == 2) {
-                if (tile < nitems) {
+                if (tile < ntiles) {
                     scale_a = wave_operand_scale(next_amax);
                     unscale_a = 1.f / scale_a;
                 }
@@ -814,7 +814,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             e.bn_partial[((size_t)blockIdx.x * 2 + which) * e.n_true + ch] = t;
         }
     }
-#undef X6_ITEM_Q0
 #undef X6_DMA_PIECE
 #undef X6_DMA_SLOT
 #undef X6_DMA_WAIT
@@ -1587,67 +1586,10 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
             }
 }
 
-// sum the position splits and scatter to the OIHW master gradient (+ bias gradient).  One thread per (tap, input channel,
-// group of four output channels): float4 loads along the packed columns, fixed summation order (splits ascending in eight
-// interleaved lanes, then a tree): deterministic, and eight 16-byte loads in flight per thread -- the loop is bound by load
-// latency (128 splits x 1.3 MB apart), and at 64 patches per GPU it is 3 % of the step.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw,
-                                                           float *__restrict__ gb, int Cin, int Cout, int CIP, int NP,
-                                                           int nsplit, int variant, int accumulate)
-{
-    const int ngrp = (Cout + 3) / 4;
-    const int total = 4 * (Cin + 1) * ngrp;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int cg = idx % ngrp;
-    int r = idx / ngrp;
-    const int ci = r % (Cin + 1);
-    const int t = r / (Cin + 1);
-    if (ci == Cin && (t != 0 || gb == nullptr)) return;
-    const float *pp = part + ((size_t)t * CIP + ci) * NP + 4 * cg;       // NP is a multiple of 16: every group is in bounds
-    const size_t stride = (size_t)4 * CIP * NP;
-    constexpr int U = 8;
-    double acc[U][4];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[u][k] = 0.0;
-    int sp = 0;
-    for (; sp + U <= nsplit; sp += U) {
-        float4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4 *>(pp + (size_t)(sp + u) * stride);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            acc[u][0] += v[u].x; acc[u][1] += v[u].y; acc[u][2] += v[u].z; acc[u][3] += v[u].w;
-        }
-    }
-    for (; sp < nsplit; ++sp) {
-        const float4 v = *reinterpret_cast<const float4 *>(pp + (size_t)sp * stride);
-        acc[0][0] += v.x; acc[0][1] += v.y; acc[0][2] += v.z; acc[0][3] += v.w;
-    }
-#pragma unroll
-    for (int h = U / 2; h > 0; h >>= 1)
-#pragma unroll
-        for (int u = 0; u < h; ++u)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[u][k] += acc[u + h][k];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int co = 4 * cg + k;
-        if (co >= Cout) break;
-        const float sv = (float)acc[0][k];
-        if (ci == Cin) {
-            gb[co] = accumulate ? gb[co] + sv : sv;
-        } else {
-            const size_t o = ((size_t)co * Cin + ci) * 4 + master_tap(t, variant);
-            gw[o] = accumulate ? gw[o] + sv : sv;
-        }
-    }
-}
-
-// the same for a partial layout with fewer than four packed columns (the thin kernels: NP = 2): one thread per element
-__global__ void wgrad_reduce1_kernel(const float *__restrict__ part, float *__restrict__ gw, float *__restrict__ gb,
+// sum the position splits and scatter to the OIHW master gradient (+ bias gradient).  One thread per output element:
+// at 64 patches per GPU this launch is latency-bound and wants every CU full of waves -- a float4-per-thread form with a
+// quarter of the threads ran 2.5x longer (130 vs 50 us at 280 -> 280, measured in the step).
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, float *__restrict__ gb,
                                      int Cin, int Cout, int CIP, int NP, int nsplit, int variant, int accumulate)
 {
     const int total = 4 * (Cin + 1) * Cout;
@@ -1925,7 +1867,7 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
         a.chunks_per_split = (a.nchunks + a.nsplit - 1) / a.nsplit;
         rc = planes == 3 ? launch_wgrad_split<3>(c, a, st) : launch_wgrad_split<2>(c, a, st);
         if (rc) return rc;
-        const int total = 4 * (Cin + 1) * ((Cout + 3) / 4);
+        const int total = 4 * (Cin + 1) * Cout;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw, gb, Cin,
                            Cout, a.nslice * 16 * c.mb, 16 * c.nb, a.nsplit, variant, accumulate);
         return mmlf_launch_status("mmlf_conv2x2_wgrad(reduce)");
@@ -1937,7 +1879,7 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
     default: rc = launch_wgrad<9>(a, st); break;
     }
     if (rc) return rc;
-    const int total = 4 * (Cin + 1) * ((Cout + 3) / 4);
+    const int total = 4 * (Cin + 1) * Cout;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw, gb, Cin,
                        Cout, a.nslice * 32, nt * 32, a.nsplit, variant, accumulate);
     return mmlf_launch_status("mmlf_conv2x2_wgrad(reduce)");
@@ -2005,21 +1947,6 @@ static bool conv_sixteen_waves(int planes, int np, const Grid &g)
     return on && planes == 2 && np == 80 && g.P + 513 <= 640;
 }
 
-// work items of a persistent launch: the full tiles, or -- when the tiles left for the last round fill at most half the
-// grid -- those tiles as two half tiles each (conv4tap_x6s_kernel).  MMLF_CONV_HALF=0 turns the halves off.
-struct ConvItems { int nitems, split_from; };
-static ConvItems conv_items(long long ntiles, long long grid, bool allow)
-{
-    static const int on = [] { const char *e = getenv("MMLF_CONV_HALF"); return e ? atoi(e) : 1; }();
-    ConvItems it = {(int)ntiles, 0x7fffffff};
-    const long long full = ntiles / grid * grid, rem = ntiles - full;
-    if (on && allow && rem > 0 && 2 * rem <= grid) {
-        it.split_from = (int)full;
-        it.nitems = (int)(full + 2 * rem);
-    }
-    return it;
-}
-
 template <int G, int PL, int EPI>
 static int launch_conv_x6s_epi(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
@@ -2041,16 +1968,13 @@ static int launch_conv_x6s_epi(const ConvArgs &a, long long ntiles, hipStream_t 
             constexpr size_t lds_pipe16 = MMLF_RING16 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
             const size_t lds16 = lds_pipe16 + (a.bn_partial ? lds_stats16 : 0);
             const long long grid16 = conv_split_blocks(G, ntiles, 16);
-            const ConvItems it16 = conv_items(ntiles, grid16, false);
-            hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI, 16>), dim3((unsigned)grid16), dim3(1024), lds16, st, a, it16.nitems,
-                               it16.split_from);
+            hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI, 16>), dim3((unsigned)grid16), dim3(1024), lds16, st, a, (int)ntiles);
             return mmlf_launch_status("mmlf_conv2x2_h2(16 waves)");
         }
     }
     const size_t lds = lds_pipe + (a.bn_partial ? lds_stats : 0);
     const long long grid = conv_split_blocks(G, ntiles);
-    const ConvItems it = conv_items(ntiles, grid, G > 6);      // (one workgroup per CU: a half tile leaves one wave per SIMD)
-    hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI>), dim3((unsigned)grid), dim3(512), lds, st, a, it.nitems, it.split_from);
+    hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI>), dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
     return mmlf_launch_status(PL == 3 ? "mmlf_conv2x2_split" : "mmlf_conv2x2_h2");
 }
 
@@ -2164,6 +2088,15 @@ extern "C" int mmlf_pack_filter_h2(const float *w, void *packed, int Cout, int C
     hipLaunchKernelGGL(pack_filter_h2_kernel, dim3(NP), dim3(256), 0, (hipStream_t)stream, w, (unsigned short *)packed,
                        Cout, Cin, variant, dgrad, nchunk, NP, tail);
     return mmlf_launch_status("mmlf_pack_filter_h2");
+}
+
+extern "C" int mmlf_packed_filter_h2_columns(int N) { return x6_np(N); }
+
+extern "C" int mmlf_pack_filters_h2(const mmlf_pack_desc *table, int n, int total_columns, void *stream)
+{
+    MMLF_CHECK_ARG(table && n > 0 && total_columns > 0, "mmlf_pack_filters_h2: empty table");
+    hipLaunchKernelGGL(pack_filters_h2_kernel, dim3((unsigned)total_columns), dim3(256), 0, (hipStream_t)stream, table, n);
+    return mmlf_launch_status("mmlf_pack_filters_h2");
 }
 
 extern "C" int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const float *bias, int N,
@@ -2444,7 +2377,7 @@ extern "C" int mmlf_conv2x2_wgrad_thin(const float *in, int cs_in, int Cin, cons
     const int nwaves = thin_wgrad_waves();
     hipLaunchKernelGGL(thin_wgrad_kernel, dim3(nwaves / 4), dim3(256), 0, st, a);
     const int total = 4 * (Cin + 1) * Cout;
-    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw_oihw, gb, Cin, Cout,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, gw_oihw, gb, Cin, Cout,
                        Cin + 1, THIN_MAXN, nwaves, variant, accumulate);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_thin");
 }

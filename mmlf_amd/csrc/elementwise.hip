@@ -7,7 +7,7 @@
 thread_local char g_mmlf_err[512] = "";
 
 extern "C" const char *mmlf_last_error(void) { return g_mmlf_err; }
-extern "C" int mmlf_abi_version(void) { return 3; }
+extern "C" int mmlf_abi_version(void) { return 4; }
 extern "C" int64_t mmlf_amax_entries(int B, int H, int W)
 {
     if (B <= 0 || H <= 0 || W <= 0) return -1;
@@ -1149,6 +1149,41 @@ extern "C" int mmlf_zero_slack(float *grid, int cs, int B, int H, int W, float *
     hipLaunchKernelGGL(zero_slack_kernel, dim3(ew_blocks(head + tail + n_amax)), dim3(256), 0, (hipStream_t)stream, grid,
                        head, tail_off, tail, amax, n_amax);
     return mmlf_launch_status("mmlf_zero_slack");
+}
+
+struct ZeroSlack4 { float *buf[4]; float *amax[4]; long long head[4], tail_off[4], tail[4], end[4]; long long n_amax; };
+__global__ void zero_slack4_kernel(ZeroSlack4 z)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < z.end[3]; i += (long long)gridDim.x * blockDim.x) {
+        const int k = i < z.end[0] ? 0 : i < z.end[1] ? 1 : i < z.end[2] ? 2 : 3;
+        const long long j = i - (k ? z.end[k - 1] : 0);
+        if (j < z.head[k] + z.tail[k]) z.buf[k][j < z.head[k] ? j : z.tail_off[k] + (j - z.head[k])] = 0.f;
+        else z.amax[k][j - z.head[k] - z.tail[k]] = 0.f;
+    }
+}
+
+extern "C" int mmlf_zero_slack4(float *const grid[4], const int cs[4], float *const amax[4], int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(grid && cs && amax && B > 0 && H > 0 && W > 0, "mmlf_zero_slack4: bad argument");
+    const Grid g = make_grid(B, H, W);
+    ZeroSlack4 z;
+    long long run = 0;
+    for (int k = 0; k < 4; ++k) {
+        z.buf[k] = grid[k]; z.amax[k] = amax[k];
+        z.head[k] = z.tail_off[k] = z.tail[k] = 0;
+        if (grid[k]) {
+            MMLF_CHECK_ARG(cs[k] > 0, "mmlf_zero_slack4: cs[%d]=%d", k, cs[k]);
+            z.head[k] = (long long)(g.P + 1) * cs[k];
+            z.tail_off[k] = g.NQ * cs[k];
+            z.tail[k] = (grid_alloc_positions(g) - g.NQ) * cs[k];
+            run += z.head[k] + z.tail[k] + (amax[k] ? amax_entries(g) : 0);
+        }
+        z.end[k] = run;
+    }
+    z.n_amax = amax_entries(g);
+    if (run == 0) return 0;
+    hipLaunchKernelGGL(zero_slack4_kernel, dim3(ew_blocks(run)), dim3(256), 0, (hipStream_t)stream, z);
+    return mmlf_launch_status("mmlf_zero_slack4");
 }
 
 extern "C" int mmlf_unpack_nchw(const float *grid, int cs, float *nchw, int C, int B, int H, int W, void *stream)

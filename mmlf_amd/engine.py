@@ -43,6 +43,24 @@ class Geometry:
         call('mmlf_zero_slack', ptr(t), cs, self.B, self.H, self.W, ptr(t.absmax), _lib.stream_ptr())
         return t
 
+    def bufs(self, css, device):
+        """several grid buffers (channel strides `css`, at most four) whose slack and amax arrays ONE launch zeroes"""
+        assert 1 <= len(css) <= 4
+        if not BATCHED:
+            return [self.buf(cs, device) for cs in css]
+        ts = []
+        for cs in css:
+            t = torch.empty(self.alloc * cs, dtype=torch.float32, device=device)
+            t.absmax = torch.empty(self.amax_n, dtype=torch.float32, device=device)
+            ts.append(t)
+        import ctypes
+        n = len(ts)
+        grid = (ctypes.c_void_p * 4)(*([ptr(t) for t in ts] + [None] * (4 - n)))
+        amax = (ctypes.c_void_p * 4)(*([ptr(t.absmax) for t in ts] + [None] * (4 - n)))
+        csa = (ctypes.c_int * 4)(*(list(css) + [0] * (4 - n)))
+        call('mmlf_zero_slack4', grid, csa, amax, self.B, self.H, self.W, _lib.stream_ptr())
+        return ts
+
     def relu_mask(self, device):
         """words for the bit form of one layer's ReLU mask (mmlf_conv2x2_h2 relu_mask_out / relu_mask_in)"""
         n = int(_lib.load().mmlf_relu_mask_words(self.B, self.H, self.W))
@@ -80,6 +98,40 @@ class _Workspace:
         self.wgrad_side = None                       # workspace of weight-gradient launches on the side stream
         self.side = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
         self.partial = torch.empty(2 * 512 * max(BN_BLOCKS, LOSS_BLOCKS) + 8, dtype=torch.float64, device=device)
+
+    def packed_filters(self, items):
+        """f16-split packed forms of many filters from ONE launch (mmlf_pack_filters_h2).  items: list of
+        (key, weight tensor (Cout, Cin, 2, 2), variant, dgrad).  The descriptor table and the packed buffers persist
+        across steps as long as the same weight storage is passed (Adam updates weights in place); the contents are
+        re-made on every call.  Returns {key: packed tensor}."""
+        import numpy as np
+        lib = _lib.load()
+        sig = tuple((w.data_ptr(), w.shape[0], w.shape[1], int(var), int(dg)) for _, w, var, dg in items)
+        cache = getattr(self, '_packs', None)
+        if cache is None or cache[0] != sig:
+            desc = np.zeros(len(items), dtype=np.dtype([('w', '<u8'), ('packed', '<u8'), ('Cout', '<i4'), ('Cin', '<i4'),
+                                                         ('variant', '<i4'), ('dgrad', '<i4'), ('col0', '<i4'), ('np', '<i4')]))
+            offs, total, col = [], 0, 0
+            for i, (_, w, var, dg) in enumerate(items):
+                cout, cin = w.shape[0], w.shape[1]
+                K, N = (cout, cin) if dg else (cin, cout)
+                nbytes = int(lib.mmlf_packed_filter_h2_bytes(cs_of(K), N))
+                npk = int(lib.mmlf_packed_filter_h2_columns(N))
+                if nbytes < 0 or npk < 0:
+                    raise RuntimeError(f'pack_filters: unsupported channels K={K} N={N}')
+                offs.append((total, nbytes))
+                desc[i] = (w.data_ptr(), 0, cout, cin, int(var), int(dg), col, npk)
+                total += (nbytes + 255) // 256 * 256
+                col += npk
+            store = torch.empty(total, dtype=torch.uint8, device=self.device)
+            for i, (o, _) in enumerate(offs):
+                desc['packed'][i] = store.data_ptr() + o
+            table = torch.from_numpy(desc.view(np.uint8).copy()).to(self.device)
+            views = [store[o:o + n].view(torch.float32) for o, n in offs]
+            cache = self._packs = (sig, table, store, views, col)
+        _, table, _, views, col = cache
+        call('mmlf_pack_filters_h2', ptr(table), len(items), col, _lib.stream_ptr())
+        return {key: v for (key, _, _, _), v in zip(items, views)}
 
     def scratch(self, name, n):
         """a float32 scratch buffer of at least n elements, reused across calls of this thread on this stream"""
@@ -152,6 +204,8 @@ def _amax_of(geo, t, cs):
 
 
 CHECK_ABSMAX = bool(os.environ.get('MMLF_CHECK_ABSMAX'))
+# one launch packs every filter of a step / zeroes the slack of a block's buffers (0: per filter, per buffer)
+BATCHED = os.environ.get('MMLF_BATCHED', '1') != '0'
 # run conv1's weight gradient of the wide blocks on a side stream beside the next BatchNorm-backward kernels
 OVERLAP_WGRAD = os.environ.get('MMLF_OVERLAP_WGRAD', '1') != '0'
 
@@ -243,8 +297,36 @@ class Trunk:
         if chs % 2 or cs_of(c) != c:
             raise ValueError('native trunk needs an even model_chs with 4*model_chs a multiple of 8')
 
+    # ------------------------------------------------------------------ filters
+    def _prepack(self, p, dev, with_dgrad):
+        """every packed filter a step needs -- forward and, with_dgrad, data-gradient forms -- from ONE launch (f16 split
+        only; the other modes pack per layer).  Keys: (parameter name, variant, dgrad)."""
+        if CONV_MODE != 'f16x3' or dev.type != 'cuda' or not BATCHED:
+            return {}
+        items = []
+
+        def add(name, var, dgrad):
+            items.append(((name, var, dgrad), p[name], var, dgrad))
+
+        def block(spec, var, first):
+            thin = spec.cout <= THIN_MAX_N and spec.cin >= THIN_MIN_K      # the head's first conv runs from the master filter
+            if not thin:
+                add(f'{spec.prefix}.0.weight', var, False)
+            add(f'{spec.prefix}.2.weight', var, False)
+            if with_dgrad:
+                add(f'{spec.prefix}.2.weight', var, True)
+                if not first:
+                    add(f'{spec.prefix}.0.weight', var, True)
+
+        for _, var, blocks in self.streams:
+            for k, spec in enumerate(blocks):
+                block(spec, var, k == 0)
+        for spec in self.out_blocks:
+            block(spec, VAR_IDENTITY, False)
+        return _Workspace.get(dev).packed_filters(items)
+
     # ------------------------------------------------------------------ forward
-    def _block_fwd(self, geo, spec, var, x, cs_x, p, train, rec_list, out=None, cs_out=None, c_off=0):
+    def _block_fwd(self, geo, spec, var, x, cs_x, p, train, rec_list, out=None, cs_out=None, c_off=0, packs=None):
         """x: grid tensor (extent H,W at (1,1)).  Returns the block output grid tensor."""
         dev = x.device
         ws = _Workspace.get(dev)
@@ -252,9 +334,18 @@ class Trunk:
         cmid, cs_mid = spec.cout, cs_of(spec.cout)
         w1, b1 = p[f'{spec.prefix}.0.weight'], p[f'{spec.prefix}.0.bias']
         w2, b2 = p[f'{spec.prefix}.2.weight'], p[f'{spec.prefix}.2.bias']
-        pk1 = pack_filter(w1, var, False)
-        y = geo.buf(cs_mid, dev)
+        packs = packs or {}
         thin = cmid <= THIN_MAX_N and spec.cin >= THIN_MIN_K        # the head: matrix-vector kernels, y is tiny
+        pk1 = packs.get((f'{spec.prefix}.0.weight', var, False))
+        if pk1 is None and not thin:
+            pk1 = pack_filter(w1, var, False)
+        folded = spec.bn and not train and rec_list is None        # inference: BatchNorm folded into conv2
+        new_out = spec.bn and out is None                          # the block output is a buffer of its own
+        got = geo.bufs([cs_mid] * ((1 if folded else 2) + (1 if new_out else 0)), dev)   # one zeroing launch for all
+        y = got[0]
+        z = None if folded else got[1]
+        if new_out:
+            out, cs_out, c_off = got[-1], cs_mid, 0
         ymask = geo.relu_mask(dev) if (rec_list is not None and CONV_MODE == 'f16x3' and not thin) else None
         conv(geo, x, cs_x, spec.cin, pk1, b1, cmid, y, cs_mid, 0, H + 1, W + 1, True, mask_out=ymask, w_master=w1,
              variant=var)
@@ -269,16 +360,12 @@ class Trunk:
             call('mmlf_fold_bn_eval', ptr(w2), ptr(b2), ptr(coef), ptr(coef[C:]), ptr(w2f), ptr(b2f), C, C,
                  _lib.stream_ptr())
             pk2 = pack_filter(w2f, var, False)
-            if out is None:
-                cs_out, c_off = cs_mid, 0
-                out = geo.buf(cs_out, dev)
-                n_store = cs_out
-            else:
-                n_store = C
+            n_store = cs_out if new_out else C
             conv(geo, y, cs_mid, cmid, pk2, b2f, cmid, out, cs_out, P + 1, H, W, True, n_store=n_store, out_off=c_off)
             return out, cs_out
-        pk2 = pack_filter(w2, var, False)
-        z = geo.buf(cs_mid, dev)
+        pk2 = packs.get((f'{spec.prefix}.2.weight', var, False))
+        if pk2 is None:
+            pk2 = pack_filter(w2, var, False)
         fused_stats = spec.bn and train and CONV_MODE == 'f16x3'      # statistics from the conv epilogue
         conv(geo, y, cs_mid, cmid, pk2, b2, cmid, z, cs_mid, P + 1, H, W, False,
              bn_partial=ws.partial if fused_stats else None)
@@ -312,12 +399,7 @@ class Trunk:
                 smean.copy_(rm)
                 sinv.copy_(torch.rsqrt(rv.double() + self.eps).float())
                 rec['eval'] = True
-        if out is None:
-            cs_out, c_off = cs_mid, 0
-            out = geo.buf(cs_out, dev)
-            c_store = cs_out
-        else:
-            c_store = C
+        c_store = cs_out if new_out else C
         call('mmlf_bn_apply_relu', ptr(z), cs_mid, C, ptr(scale), ptr(shift), ptr(out), cs_out, c_off, c_store,
              B, H, W, ptr(out.absmax), _lib.stream_ptr())
         rec.update(scale=scale, shift=shift, smean=smean, sinv=sinv)
@@ -333,23 +415,25 @@ class Trunk:
         dev = h.device
         geo = Geometry(B, H, W)
         cin0 = n * c
-        tape = {'geo': geo, 'streams': [], 'out': []}
-        concat = geo.buf(4 * self.chs, dev)
+        packs = self._prepack(p, dev, save)
+        tape = {'geo': geo, 'streams': [], 'out': [], 'packs': packs}
+        concat, *xs = geo.bufs([4 * self.chs] + [cs_of(cin0)] * 3, dev)
+        xs.append(geo.buf(cs_of(cin0), dev))
         for s, (key, var, blocks) in enumerate(self.streams):
-            x = geo.buf(cs_of(cin0), dev)
+            x = xs[s]
             call('mmlf_pack_nchw', ptr(stacks[s]), cin0, ptr(x), cs_of(cin0), B, H, W, ptr(x.absmax), _lib.stream_ptr())
             cs_x = cs_of(cin0)
             recs = []
             for k, spec in enumerate(blocks):
                 last = k == len(blocks) - 1
                 x, cs_x = self._block_fwd(geo, spec, var, x, cs_x, p, train, recs if save else None,
-                                          out=concat if last else None, cs_out=4 * self.chs, c_off=s * self.chs)
+                                          out=concat if last else None, cs_out=4 * self.chs, c_off=s * self.chs, packs=packs)
             tape['streams'].append(recs)
             if not save:
                 del recs[:]
         x, cs_x = concat, 4 * self.chs
         for spec in self.out_blocks:
-            x, cs_x = self._block_fwd(geo, spec, VAR_IDENTITY, x, cs_x, p, train, tape['out'] if save else None)
+            x, cs_x = self._block_fwd(geo, spec, VAR_IDENTITY, x, cs_x, p, train, tape['out'] if save else None, packs=packs)
             if not save:
                 del tape['out'][:]
         out = torch.empty((B, self.oc, H, W), dtype=torch.float32, device=dev)
@@ -357,7 +441,7 @@ class Trunk:
         return out, (tape if save else None)
 
     # ------------------------------------------------------------------ backward
-    def _block_bwd(self, geo, rec, p, grads, gy, cs_gy, c_off, need_dx, after_bn=None, overlap=False):
+    def _block_bwd(self, geo, rec, p, grads, gy, cs_gy, c_off, need_dx, after_bn=None, overlap=False, packs=None):
         """gy: gradient w.r.t. the block output (grid, extent (H,W)).  Returns dX grid tensor.
         after_bn: called once this block's BatchNorm-backward kernels are enqueued.  overlap: run the
         first convolution's weight gradient on the side stream AFTER the data gradient is enqueued, so that
@@ -371,6 +455,16 @@ class Trunk:
         x, cs_x, y, z = rec['x'], rec['cs_x'], rec['y'], rec['z']
         pre = spec.prefix
         sp = _lib.stream_ptr
+        packs = packs or {}
+
+        def packed(name, w):
+            pk = packs.get((name, var, True))
+            return pk if pk is not None else pack_filter(w, var, True)
+
+        # this block's gradient buffers, one zeroing launch: dz (behind BatchNorm), dy, dx
+        got = geo.bufs(([cs_mid] if spec.bn else []) + [cs_mid] + ([cs_x] if need_dx else []), dev)
+        dy = got[1 if spec.bn else 0]
+        dx = got[-1] if need_dx else None
         if spec.bn:
             coef = torch.empty(3 * C, dtype=torch.float32, device=dev)
             call('mmlf_bn_bwd_reduce', ptr(gy), cs_gy, c_off, ptr(z), cs_mid, C, ptr(rec['scale']), ptr(rec['shift']),
@@ -378,7 +472,7 @@ class Trunk:
                  ptr(grads[f'{pre}.3.bias']), 1, ptr(coef), ptr(ws.partial), BN_BLOCKS, B, H, W, sp())
             if rec.get('eval'):
                 coef[C:].zero_()            # no batch-statistics terms: dz = k1 * g (dgamma / dbeta sums are the same)
-            dz = geo.buf(cs_mid, dev)
+            dz = got[0]
             call('mmlf_bn_bwd_apply', ptr(gy), cs_gy, c_off, ptr(z), cs_mid, C, ptr(rec['scale']), ptr(rec['shift']),
                  ptr(rec['smean']), ptr(coef), ptr(dz), cs_mid, B, H, W, ptr(dz.absmax), sp())
         else:
@@ -390,17 +484,15 @@ class Trunk:
         # conv2 (pad 0): weight/bias gradient, then data gradient fused with the ReLU mask of y
         wgrad(geo, y, cs_mid, C, dz, cs_mid, C, P + 1, grads[f'{pre}.2.weight'], grads[f'{pre}.2.bias'], var,
               ws.wgrad_ws(geo, C, C))
-        pk = pack_filter(w2, var, True)
-        dy = geo.buf(cs_mid, dev)
+        pk = packed(f'{pre}.2.weight', w2)
         if rec.get('ymask') is not None and CONV_MODE == 'f16x3':
             conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, mask_in=rec['ymask'])
         else:
             conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
-        del dz
+        del dz, got
         # conv1 (pad 1)
         if overlap and need_dx:
-            pk = pack_filter(w1, var, True)
-            dx = geo.buf(cs_x, dev)
+            pk = packed(f'{pre}.0.weight', w1)
             conv(geo, dy, cs_mid, C, pk, None, spec.cin, dx, cs_x, P + 1, H, W, False)
             main = torch.cuda.current_stream()
             ready = main.record_event()
@@ -416,8 +508,7 @@ class Trunk:
               ws.wgrad_ws(geo, spec.cin, C))
         if not need_dx:
             return None
-        pk = pack_filter(w1, var, True)
-        dx = geo.buf(cs_x, dev)
+        pk = packed(f'{pre}.0.weight', w1)
         conv(geo, dy, cs_mid, C, pk, None, spec.cin, dx, cs_x, P + 1, H, W, False)
         return dx
 
@@ -448,7 +539,7 @@ class Trunk:
         while recs:
             rec = recs.pop()
             wide = OVERLAP_WGRAD and rec['spec'].cin >= 128
-            res = self._block_bwd(geo, rec, p, grads, g, cs_g, 0, True, after_bn=settle, overlap=wide)
+            res = self._block_bwd(geo, rec, p, grads, g, cs_g, 0, True, after_bn=settle, overlap=wide, packs=tape.get('packs'))
             settle()                        # (blocks without BatchNorm never called it)
             if wide:
                 g, ev, keep = res
@@ -466,7 +557,7 @@ class Trunk:
             gs, cs_s, off = g, cs_g, s * self.chs
             while recs:
                 rec = recs.pop()
-                gs = self._block_bwd(geo, rec, p, grads, gs, cs_s, off, need_dx=bool(recs))
+                gs = self._block_bwd(geo, rec, p, grads, gs, cs_s, off, need_dx=bool(recs), packs=tape.get('packs'))
                 cs_s, off = rec['cs_x'], 0
             if on_done and s in (2, 0):      # shared stream nets: complete after the I (resp. H) stream
                 on_done('in_net_id' if s == 2 else 'in_net_hv')
