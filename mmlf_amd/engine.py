@@ -206,8 +206,11 @@ def _amax_of(geo, t, cs):
 CHECK_ABSMAX = bool(os.environ.get('MMLF_CHECK_ABSMAX'))
 # one launch packs every filter of a step / zeroes the slack of a block's buffers (0: per filter, per buffer)
 BATCHED = os.environ.get('MMLF_BATCHED', '1') != '0'
-# run conv1's weight gradient of the wide blocks on a side stream beside the next BatchNorm-backward kernels
-OVERLAP_WGRAD = os.environ.get('MMLF_OVERLAP_WGRAD', '1') != '0'
+# MMLF_OVERLAP_WGRAD=1: run conv1's weight gradient of the wide blocks on a side stream beside the next BatchNorm-backward
+# kernels.  Off by default since round 3: with today's kernels the step takes the same time either way (1103-1105 patches/s
+# both, A/B on one box) -- a weight-gradient workgroup fills its CU's registers, so the two kernels time-slice the CUs
+# rather than share them -- and alone the weight gradient runs 7.9 ms instead of 12.2 on the side stream.
+OVERLAP_WGRAD = os.environ.get('MMLF_OVERLAP_WGRAD', '0') != '0'
 
 
 THIN_MAX_N, THIN_MIN_K = 2, 64     # mmlf_conv2x2_thin: at most 2 output channels over at least 64 input channels

@@ -382,3 +382,24 @@ def test_f16_split_is_scale_invariant(scale, monkeypatch):
             continue        # a conv bias in front of BatchNorm has a true-zero gradient: both modes return noise
         # end-to-end gradients are ill-conditioned: 5 % relative L2 per tensor
         assert np.linalg.norm(b[1][n] - a[1][n]) <= 5e-2 * np.linalg.norm(a[1][n]) + floor, n
+
+
+def test_side_stream_weight_gradient_gives_the_same_bits(monkeypatch):
+    """MMLF_OVERLAP_WGRAD=1 (off by default since round 3) runs the wide blocks' first weight gradient on a side stream
+    with its own workspace: the gradients must be bit-identical to the single-stream order, step after step."""
+    from mmlf_amd import engine
+    from mmlf_amd.train import TrainStep
+    state = synth.synth_state(synth.param_spec(**BASE_KW), seed=9)
+    stacks, gt, mask = synth.synth_inputs(2, 32, seed=5)
+    dev = _dev()
+    t = [torch.from_numpy(s).to(dev) for s in stacks]
+    res = {}
+    for overlap in (False, True):
+        monkeypatch.setattr(engine, 'OVERLAP_WGRAD', overlap)
+        step = TrainStep(_model(BASE_KW, state), lr=1e-3)
+        for it in range(3):
+            step(*t, torch.from_numpy(gt).to(dev), torch.from_numpy(mask).to(dev), it + 1)
+        torch.cuda.synchronize()
+        res[overlap] = (step.grad.clone(), step.flat.clone())
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    assert torch.isfinite(res[True][0]).all() and float(res[True][0].abs().max()) > 0

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for one round: kernel-trace stats of bench.py and the three PMC passes (FETCH_SIZE / WRITE_SIZE /
 # MFMA-busy + clock), summarised into gpurun_out/prof_$TAG/; copy what is to be judged into profiles/.
 #   gpurun -- bash tools/profile_round.sh r02
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
