@@ -31,7 +31,7 @@ BASE_KW = dict(model_ksize=2, model_in_blocks=3, model_out_blocks=8, model_chs=7
 GFLOP_PER_PATCH = {'base': 268.373, 'upr': 268.437, 'dpp': 277.718}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 / f16 MFMA; the split kernels spend 3 (f16x3) or 6 (bf16x6) passes per f32 product
-PMC_SUMMARIES = [os.path.join(ROOT, 'profiles', n) for n in ('r02_pmc_bs512_base_summary.json',
+PMC_SUMMARIES = [os.path.join(ROOT, 'profiles', n) for n in ('r03_pmc_bs512_base_summary.json', 'r02_pmc_bs512_base_summary.json',
                                                                 'r01i_pmc_bs512_base_summary.json')]
 KW_EXTRA = {'base': {}, 'upr': {'model_uncert': True}, 'dpp': {'model_discrete': True}}
 
@@ -39,7 +39,8 @@ KW_EXTRA = {'base': {}, 'upr': {'model_uncert': True}, 'dpp': {'model_discrete':
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` (a name prefix: the epilogue variants of one kernel template are averaged,
     weighted by their launch counts) from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
-    runs of this same command; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes)."""
+    runs of this same command, tools/profile_round.sh; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes).
+    Counters cannot be read from inside a timed run: this is the newest committed measurement of the same kernels."""
     for path in PMC_SUMMARIES:
         try:
             with open(path) as f:
@@ -339,8 +340,9 @@ def main():
             line['roofline_wgrad'] = {
                 'bound': 'mfma', 'achieved': round(wach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                 'frac': round(wach / peak, 4), 'traffic': pmc_traffic(wname.split('<')[0]) if args.global_batch == 512 and world == 1 else None,
-                'kernel': wname + ' + scales / reduce launches (280->280 weight + bias gradient, in the step: the '
-                                  'conv1 gradients run on a side stream beside the BatchNorm-backward kernels)',
+                'kernel': wname + ' + scales / reduce launches (280->280 weight + bias gradient, in the step'
+                                  + ('; MMLF_OVERLAP_WGRAD=1: the conv1 gradients run on a side stream beside the '
+                                     'BatchNorm-backward kernels)' if engine.OVERLAP_WGRAD else ')'),
                 'launches': len(wprof), 'avg_ms': round(1e3 * wsecs / len(wprof), 3),
                 'avg_ms_main_stream': avg(main), 'avg_ms_side_stream': avg(side),
                 'algorithmic_bytes': round(2.0 * B * 98 * 98 * 280 * 4) if args.patch == 96 else None}
