@@ -97,3 +97,17 @@ def nll_laplace(mpi, mean, logvar, mask=None):
     if mask is not None:
         return (nllh * mask).sum() / mask.sum()
     return nllh.mean()
+
+
+def nll_discrete(weights, posterior, vmin=None, vmax=None, mask=None):
+    """validate/cli.py:52-73: negative log likelihood of the multi-plane target under a discrete posterior (the 7.0 is
+    the reference's bin-width constant).  Does not modify its inputs."""
+    eps = 0.00001
+    weights = _f64(weights) + eps
+    posterior = posterior + eps                      # the reference keeps the model's float32 here
+    weights = weights / weights.sum(1, keepdim=True)
+    posterior = posterior / (posterior.sum(1, keepdim=True) * 7.0)
+    nllh = (weights * -torch.log(posterior)).sum(1)
+    if mask is not None:
+        return (nllh * mask).sum() / mask.sum()
+    return nllh.mean()

@@ -501,6 +501,50 @@ def g10_pfm():
     print('G10 pfm', {k: v.shape for k, v in rec.items() if k.endswith('bytes')})
 
 
+def g10_validate():
+    """the per-scene body of validate/cli.py:258-345 on FIXED model outputs (a stub model), for the three head kinds and
+    the ensemble: MSE / BadPix with the 15-px margin, the discretised predictive distribution, KL divergences (all,
+    multimodal, unimodal pixels), NLL -- computed with the reference's own helpers"""
+    import contextlib
+    import io
+    from mmlf.validate import cli as vcli
+    rs = np.random.RandomState(41)
+    H = W = 40
+    P, S = 3, 5
+    mpi = rs.uniform(0.0, 1.0, (1, P, 5, H, W)).astype(np.float32)
+    mpi[:, :, 4] = (6.0 * mpi[:, :, 4] - 3.0).astype(np.float32)
+    gt = mpi[:, 0, 4].copy()
+    mean = (gt + 0.05 * rs.randn(1, H, W)).astype(np.float32)
+    logvar = (-2.0 + 0.5 * rs.randn(1, H, W)).astype(np.float32)
+    scores = rs.randn(1, 108, H, W).astype(np.float32)
+    e = np.exp(scores)
+    posterior = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    means = (gt[None] + 0.3 * rs.randn(S, 1, H, W)).astype(np.float32)
+    logvars = (-2.0 + 0.5 * rs.randn(S, 1, H, W)).astype(np.float32)
+    rec = dict(mpi=mpi, gt=gt, mean=mean, logvar=logvar, scores=scores, posterior=posterior, means=means, logvars=logvars)
+    mask = ref_loss.create_mask_margin(gt.shape, 15)
+    out = {'mean': torch.from_numpy(mean)}
+    rec['mse'] = ref_loss.MaskedMSELoss()(out, torch.from_numpy(gt), mask).numpy()
+    rec['badpix'] = ref_loss.MaskedBadPix()(out, torch.from_numpy(gt), mask).numpy()
+    dist_gt = ref_dl.mpi_to_weights(torch.from_numpy(mpi), -3.5, 3.5, 108).numpy()
+    mm = vcli.multimodal_mask(mpi)
+    with contextlib.redirect_stdout(io.StringIO()):
+        kinds = {
+            'base': (vcli.mean_to_discrete(108, -3.5, 3.5, mean), vcli.nll_laplace(mpi, mean, np.zeros_like(mean), None)),
+            'upr': (vcli.laplace_to_discrete(108, -3.5, 3.5, mean, logvar), vcli.nll_laplace(mpi, mean, logvar, None)),
+            'dpp': (posterior.copy(), vcli.nll_discrete(dist_gt.copy(), posterior.copy(), -3.5, 3.5, None)),
+            # validate/cli.py:302,318: exp(logvars) goes in under the name `logvars`
+            'ese': (vcli.lmm_to_discrete(108, -3.5, 3.5, means, np.exp(logvars)), 0.0),
+        }
+        for k, (dist, nll) in kinds.items():
+            rec[f'{k}/nll'] = np.float64(nll)
+            rec[f'{k}/kld'] = np.float64(vcli.kl_divergence(dist.copy(), dist_gt.copy()))
+            rec[f'{k}/kld_mm'] = np.float64(vcli.kl_divergence(dist.copy(), dist_gt.copy(), mm))
+            rec[f'{k}/kld_um'] = np.float64(vcli.kl_divergence(dist.copy(), dist_gt.copy(), 1.0 - mm))
+    np.savez_compressed(os.path.join(HERE, 'g10_validate.npz'), **rec)
+    print('G10 validate', {k: float(v) for k, v in rec.items() if '/' in k})
+
+
 def g10_unet():
     """--model_unet (reference feed_forward.py:189-204, unet.py): outputs only, weights by synth.formula_state"""
     kw = dict(TINY_KW, model_unet=True, model_uncert=True)
@@ -587,6 +631,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'g10u':
         g10_unet()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g10v':
+        g10_validate()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g10':
         g10_pfm()
         sys.exit(0)
@@ -608,6 +655,7 @@ if __name__ == '__main__':
     g8_extras()
     g10_pfm()
     g10_unet()
+    g10_validate()
     g11_conditioned_f64()
     sizes = {f: os.path.getsize(os.path.join(HERE, f)) for f in sorted(os.listdir(HERE))
              if f.endswith('.npz')}

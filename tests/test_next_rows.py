@@ -116,3 +116,69 @@ def test_multimodal_train_step(dev, variant):
         ref = p.grad.reshape(-1).cpu()
         got = st.grad[o:o + cnt].cpu()
         assert float((got - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-6, n
+
+
+class _StubModel(torch.nn.Module):
+    """returns fixed head outputs: pins the validation loop itself, not the network"""
+
+    def __init__(self, out, disp_min=-3.5, disp_max=3.5, steps=108):
+        super().__init__()
+        self.out, self.disp_min, self.disp_max, self.steps = out, disp_min, disp_max, steps
+
+    def forward(self, h, v, i, d):
+        return dict(self.out)
+
+
+@pytest.mark.parametrize('dev', DEVICES)
+@pytest.mark.parametrize('kind', ['base', 'upr', 'dpp', 'ese'])
+def test_validation_loop_vs_reference_helpers(kind, dev, tmp_path):
+    """reference validate/cli.py:249-351 per scene: MSE / BadPix (15-px margin), discretised predictive distribution,
+    KL divergences over all / multimodal / unimodal pixels, NLL -- golden from the reference's own helper functions on
+    fixed head outputs (tests/golden/g10_validate.npz) -- and the result files it writes"""
+    from mmlf_amd import pfm, validate
+    g = load_golden('g10_validate.npz')
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    out = {'mean': t('mean'), 'logvar': None, 'scores': None, 'one_hot': None, 'posterior': None}
+    if kind == 'upr':
+        out['logvar'] = t('logvar')
+    if kind == 'dpp':
+        out.update(scores=t('scores'), posterior=t('posterior'), logvar=t('logvar'))
+    if kind == 'ese':
+        out = {'mean': t('mean'), 'logvar': t('logvar'), 'means': t('means'), 'logvars': t('logvars'), 'posterior': t('posterior')}
+    H, W = g['gt'].shape[1:]
+    views = [torch.rand(1, 3, 3, H, W) for _ in range(4)]
+    scene = (*views, torch.rand(1, 3, H, W), t('gt'), t('mpi'), None, torch.tensor([[1]]))
+    rows, avg = validate.validate_scenes(_StubModel(out), [scene], out_dir=str(tmp_path), scene_names=['a', 'b'])
+    assert len(rows) == 1
+    np.testing.assert_allclose(avg['mse'], g['mse'], rtol=1e-5)
+    np.testing.assert_allclose(avg['badpix'], g['badpix'], rtol=1e-6)
+    for key in ('kld', 'kld_mm', 'kld_um', 'nll'):
+        np.testing.assert_allclose(avg[key], g[f'{kind}/{key}'], rtol=2e-5, atol=1e-9, err_msg=key)
+    np.testing.assert_array_equal(pfm.load(str(tmp_path / 'scenes' / 'b' / 'result.pfm')), g['mean'][0][::-1])
+    assert (tmp_path / 'ours' / 'runtimes' / 'b.txt').exists()
+    if kind == 'ese':
+        lmm = np.load(str(tmp_path / 'scenes' / 'b' / 'gmm.npy'))
+        np.testing.assert_allclose(lmm[0], g['means'][:, 0], rtol=0, atol=0)
+        np.testing.assert_allclose(lmm[1], np.exp(g['logvars'][:, 0]), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_validation_loop_runs_the_ensemble_on_the_gpu(tmp_path):
+    """--val_ensamble end to end on the HIP path: 70 members, fused reduce, Laplace-mixture distribution metrics, files"""
+    from mmlf_amd import pfm, validate
+    from mmlf_amd.ensamble import Ensamble
+    kw = dict(TINY_KW, model_uncert=True)
+    model = FeedForward(**kw)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.synth_state(synth.param_spec(**kw), 4).items()})
+    model.cuda().eval()
+    ens = Ensamble(model, -3.5, 3.5, 0.1)
+    scenes = []
+    for k in range(2):
+        s = synth.synth_scene(k, 24, 24)
+        scenes.append(tuple(torch.from_numpy(np.asarray(a)).unsqueeze(0).cuda() for a in s[:8]) + (torch.tensor([[k]]),))
+    rows, avg = validate.validate_scenes(ens, scenes, out_dir=str(tmp_path), scene_names=['s0', 's1'], margin=4)
+    assert len(rows) == 2 and all(np.isfinite(list(r.values())).all() for r in rows)
+    assert avg['kld'] > 0 and avg['mse'] > 0
+    assert pfm.load(str(tmp_path / 'ours' / 'disp_maps' / 's1.pfm')).shape == (24, 24)
+    assert np.load(str(tmp_path / 'scenes' / 's0' / 'gmm.npy')).shape == (2, 70, 24, 24)
+    assert np.load(str(tmp_path / 'scenes' / 's0' / 'posterior.npy')).shape == (70, 24, 24)
