@@ -577,3 +577,42 @@ np.savez(sys.argv[1], y=y.cpu().numpy(), z=z.cpu().numpy(), g=g.cpu().numpy(), m
         assert np.array_equal(outs[0][key], outs[1][key]), key
     # the per-workgroup partial sums are grouped differently (256 vs 512 positions per workgroup): equal after the sum
     np.testing.assert_allclose(outs[0]['part'], outs[1]['part'], rtol=1e-12)
+
+
+def test_batched_filter_packing_and_slack_zeroing_equal_the_per_layer_calls():
+    """mmlf_pack_filters_h2 (every filter of a step from one launch) and mmlf_zero_slack4 (a block's buffers from one
+    launch) must write the bytes of the per-filter / per-buffer entry points"""
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    dev = _dev()
+    gen = torch.Generator(device=dev).manual_seed(12)
+    shapes = [(70, 27, 1, False), (70, 70, 0, False), (70, 70, 2, True), (280, 280, 0, False), (280, 280, 0, True),
+              (1, 280, 0, True), (108, 280, 0, False), (108, 108, 0, True), (2, 2, 0, False)]
+    ws = [(torch.rand((co, ci, 2, 2), device=dev, generator=gen) - 0.5) * (10.0 ** (k - 4)) for k, (co, ci, _, _) in enumerate(shapes)]
+    items = [((f'w{k}', var, dg), w, var, dg) for k, (w, (_, _, var, dg)) in enumerate(zip(ws, shapes))]
+    work = engine._Workspace.get(dev)
+    packs = work.packed_filters(items)
+    for (key, w, var, dg) in items:
+        single = engine.pack_filter(w, var, dg)
+        assert packs[key].numel() == single.numel(), key
+        assert torch.equal(packs[key].view(torch.int32), single.view(torch.int32)), key
+    # a second call with the same weight storage reuses table and buffers and re-packs the (changed) contents
+    ws[3].mul_(3.0)
+    again = work.packed_filters(items)
+    assert again[items[3][0]].data_ptr() == packs[items[3][0]].data_ptr()
+    assert torch.equal(again[items[3][0]].view(torch.int32), engine.pack_filter(ws[3], 0, False).view(torch.int32))
+    # zero_slack4
+    geo = engine.Geometry(3, 7, 11)
+    css = [8, 72, 280]
+    a = [torch.full((geo.alloc * cs,), float('nan'), device=dev) for cs in css]
+    am = [torch.full((geo.amax_n,), float('nan'), device=dev) for _ in css]
+    b = [t.clone() for t in a]
+    bm = [t.clone() for t in am]
+    import ctypes
+    call('mmlf_zero_slack4', (ctypes.c_void_p * 4)(*[ptr(t) for t in a], None), (ctypes.c_int * 4)(*css, 0),
+         (ctypes.c_void_p * 4)(*[ptr(t) for t in am], None), geo.B, geo.H, geo.W, _lib.stream_ptr())
+    for t, m, cs in zip(b, bm, css):
+        call('mmlf_zero_slack', ptr(t), cs, geo.B, geo.H, geo.W, ptr(m), _lib.stream_ptr())
+    for x, y in zip(a + am, b + bm):
+        assert torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0))
+    assert all(float(m.abs().sum()) == 0 for m in am)
