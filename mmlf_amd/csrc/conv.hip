@@ -75,6 +75,17 @@ struct ConvArgs {
 //  * addressing: buffer instructions on a wave-uniform tile descriptor + 32-bit per-lane byte offsets
 //    (the column-block offset folds into the instruction's immediate);
 //  * bias and (data-gradient) ReLU-reference values are loaded in batches ahead of their use.
+#ifndef MMLF_PRIO_LEVELS
+#define MMLF_PRIO_LEVELS 0   // levels of the progress-inverse wave priority in the chunk loops (0 = off; at most 4)
+#endif
+// s_setprio takes an immediate: the level folds to a constant once the column-block loops are unrolled
+__device__ __forceinline__ void mmlf_set_prio(int level)
+{
+    if (level >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (level == 2) __builtin_amdgcn_s_setprio(2);
+    else if (level == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 #ifndef MMLF_RING16
 #define MMLF_RING16 3   // pipeline depth of the sixteen-wave conv variant (LDS: 30 KB per buffer + 20 KB; 4 measures the same)
 #endif
@@ -708,6 +719,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+#if MMLF_PRIO_LEVELS > 1
+            // Progress-inverse wave priority.  The two waves of a SIMD share its matrix pipe, and the arbiter serves the
+            // older one first: it runs through its column blocks at full speed, waits at the chunk's barrier, and its
+            // partner finishes alone, at the 50 % matrix-pipe density of a single wave's instruction stream (the
+            // wave's own clock: 3 300 + 1 480 cycles against 4 680 + 110).  A wave that is further into its chunk
+            // lowers its priority, so whichever wave is behind is served first and the pair reaches the barrier together.
+            if (G >= 8 && (g == 0 || (g * MMLF_PRIO_LEVELS) / G != ((g - 1) * MMLF_PRIO_LEVELS) / G))
+                mmlf_set_prio(MMLF_PRIO_LEVELS - 1 - (g * MMLF_PRIO_LEVELS) / G);
+#endif
             if (EARLY && g == G - 2) {
                 // every LDS read of this chunk has been requested (weights run two column blocks ahead): wait for them and
                 // for the next chunk's DMA pieces, pass the barrier, then ask for the next chunk's activations
@@ -1519,6 +1539,8 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
             _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                                 \
                 af[mb][pl] = tr_frag(cur + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);                        \
         _Pragma("unroll") for (int nb = 0; nb < NBH; ++nb) {                                                 \
+            if (MMLF_PRIO_LEVELS > 1 && (nb == 0 || (nb * MMLF_PRIO_LEVELS) / NBH != ((nb - 1) * MMLF_PRIO_LEVELS) / NBH)) \
+                mmlf_set_prio(MMLF_PRIO_LEVELS - 1 - (nb * MMLF_PRIO_LEVELS) / NBH);                        \
             if (EARLY && (STAGE) && nb == NBH - 2) {                                                         \
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* my staging stores and fragment reads */ \
                 __syncthreads();                                                                             \
