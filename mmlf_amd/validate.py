@@ -31,6 +31,8 @@ def validate_scenes(model, scenes, val_disp_min=-3.5, val_disp_max=3.5, margin=1
     DataLoader does.  Returns (per-scene list of dicts, dict of averages = the reference's table row)."""
     import time
     from . import dl, metrics, results
+    if out_dir is not None and scene_names is None:
+        raise ValueError('validate_scenes: out_dir needs scene_names (the dataset\'s scenes_names, indexed by `index`)')
     model.eval()
     inner = getattr(model, 'model', model)                       # Ensamble wraps the network
     inner = getattr(inner, 'module', inner)
