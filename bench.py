@@ -31,27 +31,31 @@ BASE_KW = dict(model_ksize=2, model_in_blocks=3, model_out_blocks=8, model_chs=7
 GFLOP_PER_PATCH = {'base': 268.373, 'upr': 268.437, 'dpp': 277.718}
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 / f16 MFMA; the split kernels spend 3 (f16x3) or 6 (bf16x6) passes per f32 product
-PMC_SUMMARIES = [os.path.join(ROOT, 'profiles', n) for n in ('r03_pmc_bs512_base_summary.json', 'r02_pmc_bs512_base_summary.json',
-                                                                'r01i_pmc_bs512_base_summary.json')]
+# the committed rocprofv3 PMC passes `roofline.traffic` is read from (tools/profile_round.sh writes it; ONE file, named in
+# the line as `traffic_source`: an older round's numbers are never substituted silently)
+PMC_SUMMARY = os.environ.get('MMLF_PMC_SUMMARY', os.path.join('profiles', 'r04_pmc_bs512_base_summary.json'))
 KW_EXTRA = {'base': {}, 'upr': {'model_uncert': True}, 'dpp': {'model_discrete': True}}
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` (a name prefix: the epilogue variants of one kernel template are averaged,
-    weighted by their launch counts) from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
-    runs of this same command, tools/profile_round.sh; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes).
-    Counters cannot be read from inside a timed run: this is the newest committed measurement of the same kernels."""
-    for path in PMC_SUMMARIES:
-        try:
-            with open(path) as f:
-                d = json.load(f)
-            hit = [v for k, v in d.items() if kernel in k and v.get('avg_ns', 0) > 4e6]     # the 280-wide launches
-            if hit:
-                n = sum(v['launches'] for v in hit)
-                return round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit) / n)
-        except (OSError, ValueError, KeyError):
-            pass
-    return None
+    """(HBM bytes per launch of `kernel`, source file) -- `kernel` is a name prefix: the epilogue variants of one kernel
+    template are averaged, weighted by their launch counts -- from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this same command, tools/profile_round.sh; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE, KB ->
+    bytes).  Counters cannot be read from inside a timed run: this is the committed measurement of the same kernels; if
+    the file is missing or does not hold the kernel, traffic is null and stderr says so."""
+    path = PMC_SUMMARY if os.path.isabs(PMC_SUMMARY) else os.path.join(ROOT, PMC_SUMMARY)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        hit = [v for k, v in d.items() if kernel in k and v.get('avg_ns', 0) > 3e6]     # the 280-wide launches
+        if hit:
+            n = sum(v['launches'] for v in hit)
+            return round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit) / n), PMC_SUMMARY
+        why = f'no launches of {kernel} in {PMC_SUMMARY}'
+    except (OSError, ValueError, KeyError) as e:
+        why = f'{PMC_SUMMARY}: {e}'
+    print(f'bench.py: roofline.traffic unavailable ({why}); run tools/profile_round.sh', file=sys.stderr, flush=True)
+    return None, f'unavailable: {why}'
 
 
 def host_threads():
@@ -177,14 +181,15 @@ def autograd_leg(variant, B, patch, dev, steps, ref_ms):
     return res
 
 
-def ese_leg(dev, peak, size=512):
-    """BASELINE.json configs[4] on one GPU: one 512x512 light field through the 70-member Ensamble (eval)"""
+def ese_leg(dev, peak, size=512, seed=2):
+    """BASELINE.json configs[4] on one GPU: one 512x512 light field through the 70-member Ensamble (eval;
+    reference mmlf/model/ensamble.py:58-118)"""
     from mmlf_amd.ensamble import Ensamble
     from mmlf_amd.feed_forward import FeedForward
     torch.manual_seed(0)
     model = FeedForward(**dict(BASE_KW, model_uncert=True)).to(dev).eval()
     ens = Ensamble(model, -3.5, 3.5, 0.1).eval()
-    gen = torch.Generator(device=dev).manual_seed(2)
+    gen = torch.Generator(device=dev).manual_seed(seed)
     stacks = [torch.rand((1, 9, 3, size, size), device=dev, generator=gen) for _ in range(4)]
     times = []
     with torch.no_grad():
@@ -215,6 +220,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the extra exact-f32-MFMA measurement')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the UPR / DPP / shard-64 / ESE measurements')
+    ap.add_argument('--ese-size', type=int, default=512, help='frame size of the ESE legs (BASELINE.json configs[4]: 512)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo: rehearsal of the N>1 path with every rank on whatever GPUs exist (one is enough)')
     args = ap.parse_args()
@@ -262,33 +268,44 @@ def main():
     sync()
     dt = time.time() - t0
     prof, engine.PROFILE = engine.PROFILE, None
-    # second leg (N=1 only): the same step on the exact-f32 MFMA kernels, for comparison
-    f32_leg = None
-    if world == 1 and not args.no_f32_leg and engine.CONV_MODE != 'f32':
-        mode = engine.CONV_MODE
-        engine.CONV_MODE = 'f32'
-        step(*stacks, gt, mask, it)
-        sync()
-        engine.PROFILE = []
-        t1 = time.time()
-        for _ in range(2):
+    # further legs (N=1 only): the same step in the two arithmetic modes that carry no precision asterisk -- the exact-f32
+    # MFMA kernels (5 steps) and the exact 3 x bf16 split (3 steps) -- same tensors, same shapes
+    mode_legs = {}
+    if world == 1 and not args.no_f32_leg:
+        for mode_name, nsteps in (('f32', 5), ('bf16x6', 3)):
+            if engine.CONV_MODE == mode_name:
+                continue
+            mode = engine.CONV_MODE
+            engine.CONV_MODE = mode_name
             step(*stacks, gt, mask, it)
-        sync()
-        dt1 = time.time() - t1
-        p1, engine.PROFILE = engine.PROFILE, None
-        engine.CONV_MODE = mode
-        p1 = [r for r in p1 if r[0] == 'conv']
-        s1 = sum(e0.elapsed_time(e1) for _, _, e0, e1 in p1) * 1e-3
-        a1 = sum(f for _, f, _, _ in p1) / s1 / 1e12 if s1 > 0 else 0.0
-        f32_leg = {'value': round(args.global_batch * 2 / dt1, 3), 'unit': 'patches/s', 'steps': 2,
-                   'kernel': 'conv4tap_kernel<9> (v_mfma_f32_32x32x2_f32)', 'achieved': round(a1, 2),
-                   'peak': PEAK_F32_MFMA_TFLOPS, 'frac': round(a1 / PEAK_F32_MFMA_TFLOPS, 4)}
+            sync()
+            engine.PROFILE = []
+            t1 = time.time()
+            for _ in range(nsteps):
+                step(*stacks, gt, mask, it)
+            sync()
+            dt1 = time.time() - t1
+            p1, engine.PROFILE = engine.PROFILE, None
+            engine.CONV_MODE = mode
+            p1 = [r for r in p1 if r[0] == 'conv']
+            s1 = sum(e0.elapsed_time(e1) for _, _, e0, e1 in p1) * 1e-3
+            a1 = sum(f for _, f, _, _ in p1) / s1 / 1e12 if s1 > 0 else 0.0
+            pk = PEAK_F32_MFMA_TFLOPS if mode_name == 'f32' else PEAK_BF16_MFMA_TFLOPS / 6
+            mode_legs[mode_name] = {
+                'value': round(args.global_batch * nsteps / dt1, 3), 'unit': 'patches/s', 'steps': nsteps,
+                'ms_per_step': round(1e3 * dt1 / nsteps, 2),
+                'kernel': ('conv4tap_kernel<9> (v_mfma_f32_32x32x2_f32)' if mode_name == 'f32'
+                           else 'conv4tap_x6s_kernel<18, 3, EPI> (v_mfma_f32_16x16x32_bf16, six cross terms)'),
+                'achieved': round(a1, 2), 'peak': round(pk, 1), 'frac': round(a1 / pk, 4),
+                'launches': len(p1), 'avg_ms': round(1e3 * s1 / max(1, len(p1)), 3)}
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     loss_val = float(loss)
 
+    n_buckets = len(step.buckets.ranges) if step.buckets is not None else 0
+    grad_bytes = int(step.grad.numel()) * 4
     allreduce_ms = None
     if step.buckets is not None and step.buckets.wait_events:
         # per step: how long the compute stream stood behind the bucket all-reduces after backward had been enqueued
@@ -296,6 +313,23 @@ def main():
                           dtype=torch.float64, device=dev)
         dist.all_reduce(ar, op=dist.ReduceOp.MAX)
         allreduce_ms = float(ar)
+    # BASELINE.json configs[4] under --gpus N: replicas only -- every rank runs its own 512x512 light field
+    # through the 70-member Ensamble, no collective on the data path; reported as max-over-ranks seconds per scene
+    ese_rep = None
+    if world > 1 and not args.no_extra_legs:
+        passes_ = {'f16x3': 3, 'bf16x6': 6}.get(engine.CONV_MODE)
+        peak_ = PEAK_BF16_MFMA_TFLOPS / passes_ if passes_ else PEAK_F32_MFMA_TFLOPS
+        del step, stacks, gt, mask
+        torch.cuda.empty_cache()
+        sync()
+        mine = ese_leg(dev, peak_, size=args.ese_size, seed=2 + rank)
+        worst = torch.tensor([mine['value']], dtype=torch.float64, device=dev)
+        ok = torch.tensor([1.0 if mine['finite'] else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        ese_rep = dict(mine, value=round(float(worst), 4), scenes=world, scenes_per_s=round(world / float(worst), 3),
+                       finite=bool(float(ok) > 0),
+                       note='one light field per GPU, no data-path collective; value = slowest rank, scenes_per_s = N / value')
     if rank == 0:
         value = args.global_batch * args.steps / dt
         wprof = [r for r in prof if r[0].startswith('wgrad')]
@@ -310,6 +344,7 @@ def main():
         dtype = {'f16x3': 'f32 via 2 x f16 operand split (22 significant bits per operand, locally scaled; 3 MFMA '
                           'passes, f32 accumulate)',
                  'bf16x6': 'f32 via exact 3 x bf16 operand split (6 MFMA passes, f32 accumulate)'}.get(engine.CONV_MODE, 'f32')
+        traffic = pmc_traffic(kname) if args.global_batch == 512 and world == 1 else (None, 'n/a: not the bs=512 single-GPU shape')
         line = {
             'metric': '96x96 EPI patches/sec fwd+bwd, bs=512', 'value': round(value, 3), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
@@ -321,7 +356,7 @@ def main():
             'whole_step_tflops': round(value * GFLOP_PER_PATCH[args.variant] / 1e3, 2),
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1),
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                         'traffic': pmc_traffic(kname) if args.global_batch == 512 and world == 1 else None,
+                         'traffic': traffic[0], 'traffic_source': traffic[1],
                          'kernel': kname + (', EPI> (280->280 forward + data-gradient launches, all epilogue variants)' if split
                                             else ' (280->280 forward + data-gradient launches)'),
                          'peak_is': (f'dense 16-bit MFMA 2500 TFLOP/s / {passes} passes per f32 product' if split
@@ -337,9 +372,11 @@ def main():
             main = [r for r in wprof if r[0] == 'wgrad']
             avg = lambda rs: round(sum(e0.elapsed_time(e1) for _, _, e0, e1 in rs) / len(rs), 3) if rs else None
             wname = f'wgrad4tap_x6w_kernel<3, 9, {2 if passes == 3 else 3}>' if split else 'wgrad4tap_kernel<9>'
+            wtraffic = (pmc_traffic(wname.split('<')[0]) if args.global_batch == 512 and world == 1
+                        else (None, 'n/a: not the bs=512 single-GPU shape'))
             line['roofline_wgrad'] = {
                 'bound': 'mfma', 'achieved': round(wach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                'frac': round(wach / peak, 4), 'traffic': pmc_traffic(wname.split('<')[0]) if args.global_batch == 512 and world == 1 else None,
+                'frac': round(wach / peak, 4), 'traffic': wtraffic[0], 'traffic_source': wtraffic[1],
                 'kernel': wname + ' + scales / reduce launches (280->280 weight + bias gradient, in the step'
                                   + ('; MMLF_OVERLAP_WGRAD=1: the conv1 gradients run on a side stream beside the '
                                      'BatchNorm-backward kernels)' if engine.OVERLAP_WGRAD else ')'),
@@ -347,15 +384,19 @@ def main():
                 'avg_ms_main_stream': avg(main), 'avg_ms_side_stream': avg(side),
                 'algorithmic_bytes': round(2.0 * B * 98 * 98 * 280 * 4) if args.patch == 96 else None}
         if world > 1:
-            line['config']['buckets'] = len(step.buckets.ranges)
-            line['config']['gradient_bytes'] = int(step.grad.numel()) * 4
+            line['config']['buckets'] = n_buckets
+            line['config']['gradient_bytes'] = grad_bytes
+            if ese_rep is not None:
+                line['ese_replicas'] = ese_rep
             line['allreduce_ms'] = None if allreduce_ms is None else round(allreduce_ms, 3)
             line['allreduce_note'] = ('per step, max over ranks: time the compute stream waits for the bucket all-reduces '
                                       'after backward is enqueued (0 = fully overlapped with backward)')
         if args.backend != 'nccl':
             line['config']['backend'] = args.backend + ' (rehearsal: not an xGMI measurement)'
-        if f32_leg is not None:
-            line['exact_f32_mfma_path'] = f32_leg
+        if 'f32' in mode_legs:
+            line['exact_f32_mfma_path'] = mode_legs['f32']
+        if 'bf16x6' in mode_legs:
+            line['bf16x6_path'] = mode_legs['bf16x6']
         if world == 1 and not args.no_extra_legs and args.global_batch == 512 and args.patch == 96:
             # the other BASELINE.json configs, driver-timed in the same run (single GPU each)
             del step, stacks, gt, mask
@@ -370,7 +411,7 @@ def main():
                                      for v in ('base', 'upr')}
             line['autograd_loop']['note'] = ('model(h,v,i,d) -> mmlf_amd.loss module -> loss.backward() -> torch.optim.Adam.step() '
                                              '(mmlf/train/cli.py:243-258), head outputs materialised; vs_train_step = TrainStep ms / this ms')
-            line['ese'] = ese_leg(dev, peak)
+            line['ese'] = ese_leg(dev, peak, size=args.ese_size)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.patch)
         print(json.dumps(line), flush=True)

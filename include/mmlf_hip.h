@@ -38,6 +38,10 @@ extern "C" {
 #define MMLF_TILE_POSITIONS 256
 
 const char *mmlf_last_error(void);
+/* Bumped whenever an entry point's arguments or a layout they share changes.  mmlf_abi_version() returns the value the
+ * library was BUILT with: a binding compares it with the header it was written against (mmlf_amd/_lib.py does, and reads
+ * the number from this line) before making any other call. */
+#define MMLF_ABI_VERSION 4
 int mmlf_abi_version(void);
 
 /* number of positions a grid buffer must provide for batch B and image extent H x W */

@@ -66,7 +66,18 @@ SIGNATURES = {
     'mmlf_ensamble_reduce': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
-ABI_VERSION = 4          # include/mmlf_hip.h MMLF_ABI_VERSION: bumped whenever an entry point's arguments change
+def _header_abi_version():
+    """MMLF_ABI_VERSION as include/mmlf_hip.h defines it: ONE place holds the number (the library returns the same macro)"""
+    import re
+    path = os.path.join(os.path.dirname(_HERE), 'include', 'mmlf_hip.h')
+    with open(path) as f:
+        m = re.search(r'^#define\s+MMLF_ABI_VERSION\s+(\d+)', f.read(), re.M)
+    if m is None:
+        raise RuntimeError(f'{path}: no MMLF_ABI_VERSION')
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()     # bumped whenever an entry point's arguments change
 _lib = None
 
 

@@ -86,6 +86,9 @@ __device__ __forceinline__ void mmlf_set_prio(int level)
     else if (level == 1) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
 }
+#ifndef MMLF_ABL_TERMS
+#define MMLF_ABL_TERMS 3     // cross terms of the f16 split that are evaluated (3 = the arithmetic; fewer: timing ablation)
+#endif
 #ifndef MMLF_RING16
 #define MMLF_RING16 3   // pipeline depth of the sixteen-wave conv variant (LDS: 30 KB per buffer + 20 KB; 4 measures the same)
 #endif
@@ -774,8 +777,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                 X6_TERM(0, 1);
                 X6_TERM(0, 0);
             } else {
-                H2_TERM(1, 0);
-                H2_TERM(0, 1);
+                // MMLF_ABL_TERMS (ablation builds only, WRONG results): run 2 or 1 of the three cross terms with everything
+                // else unchanged -- the time a launch would take with fewer matrix instructions per product
+                if (MMLF_ABL_TERMS >= 3) H2_TERM(1, 0);
+                if (MMLF_ABL_TERMS >= 2) H2_TERM(0, 1);
                 H2_TERM(0, 0);
             }
 #undef X6_TERM
@@ -1402,8 +1407,16 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
 // MFMAs, and chunk c+2's loads are issued.  One barrier per chunk, no phase in which the matrix
 // cores wait for staging.  155.9 KB of LDS: one workgroup per CU.
 // ---------------------------------------------------------------------------------------------
+#ifndef MMLF_WGRAD_EARLY
+#define MMLF_WGRAD_EARLY 1     // the wide weight gradient's early barrier + next-chunk fragment prefetch (16 VGPRs)
+#endif
+#ifdef MMLF_WGRAD_VGPRS        // experiment: cap the wide weight gradient's registers so that another kernel's waves fit beside it
+#define MMLF_WGRAD_ATTR __attribute__((amdgpu_num_vgpr(MMLF_WGRAD_VGPRS)))
+#else
+#define MMLF_WGRAD_ATTR
+#endif
 template <int MB, int NBH, int PL>
-__global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
+__global__ __launch_bounds__(512, 2) MMLF_WGRAD_ATTR void wgrad4tap_x6w_kernel(WgradArgs a)
 {
     constexpr int NB = 2 * NBH;
     const WgradScales sc = wgrad_scales<PL>(a);
@@ -1505,7 +1518,7 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         // store of the chunk is out by then (one piece per column block, NA + NG <= NBH - 2) and every fragment read
         // requested -- and behind it the wave asks for the NEXT chunk's first gradient fragments (the rotating slots run
         // on, NBH % 3 == 0) and its first two activation row blocks, which arrive under the last 2 x 3 x MB MFMAs.
-        constexpr bool EARLY = PL == 2 && NBH % 3 == 0 && NA + NG <= NBH - 2 && MB >= 2;
+        constexpr bool EARLY = MMLF_WGRAD_EARLY && PL == 2 && NBH % 3 == 0 && NA + NG <= NBH - 2 && MB >= 2;
         bf16x8 af[MB][PL], gfr[3][PL], afp[2][PL];
         if constexpr (EARLY) {
             const char *cur0 = smem;
@@ -1564,7 +1577,7 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
                     if (RELOAD) WW_GLOAD_G(nb - NA < NG ? nb - NA : 0, c + 2);                               \
                 }                                                                                            \
             }                                                                                                \
-            _Pragma("unroll") for (int term = 0; term < (PL == 3 ? 6 : 3); ++term)                           \
+            _Pragma("unroll") for (int term = (PL == 3 ? 0 : 3 - MMLF_ABL_TERMS); term < (PL == 3 ? 6 : 3); ++term) \
                 WW_TERM(gfr[nb % 3], term_a<PL>(term), term_b<PL>(term));                                    \
         }                                                                                                    \
         if (EARLY && (STAGE)) {                                                                              \

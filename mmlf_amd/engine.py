@@ -76,7 +76,8 @@ class Geometry:
 
 
 class _Workspace:
-    """Scratch that is reused across calls (stream-ordered, single stream), one per (device, calling thread):
+    """Scratch that is reused across calls (stream-ordered: one stream at a time, `enter_stream` orders a change of
+    stream), one per (device, calling thread):
     nn.DataParallel drives replicas from one thread per device -- and nothing stops two of them from sharing a
     device -- while autograd's backward runs on its own thread per device.  Kept in thread-local storage, so a
     workspace (an 8 MB partial-sum buffer, a side stream, up to a few hundred MB of weight-gradient scratch) dies
@@ -103,12 +104,26 @@ class _Workspace:
         """f16-split packed forms of many filters from ONE launch (mmlf_pack_filters_h2).  items: list of
         (key, weight tensor (Cout, Cin, 2, 2), variant, dgrad).  The descriptor table and the packed buffers persist
         across steps as long as the same weight storage is passed (Adam updates weights in place); the contents are
-        re-made on every call.  Returns {key: packed tensor}."""
+        re-made on every call.  Returns {key: packed tensor}.
+
+        Conditions of use (the views are handed to the tape and read again by backward):
+          * the weights must not change between a forward pass and its backward pass (the packed data-gradient forms
+            were made from the forward's weights; the reference's loop and TrainStep step the optimizer after backward);
+          * one (thread, device) workspace serves ONE stream at a time: the store is overwritten in stream order by the
+            next forward.  If the calling thread switches streams, the new stream first waits for an event recorded on the
+            old one behind this workspace's last use (`_last_use`), so a repack cannot overtake convolutions still reading
+            the store;
+          * one cache entry per signature (training packs forward + data-gradient forms, evaluation forward forms only):
+            alternating train and eval steps re-uses both instead of re-allocating and re-uploading the table."""
         import numpy as np
         lib = _lib.load()
         sig = tuple((w.data_ptr(), w.shape[0], w.shape[1], int(var), int(dg)) for _, w, var, dg in items)
-        cache = getattr(self, '_packs', None)
-        if cache is None or cache[0] != sig:
+        self.enter_stream()
+        caches = self.__dict__.setdefault('_packs', {})
+        cache = caches.get(sig)
+        if cache is None:
+            if len(caches) >= 4:                       # (weights re-allocated: drop the stale entries)
+                caches.clear()
             desc = np.zeros(len(items), dtype=np.dtype([('w', '<u8'), ('packed', '<u8'), ('Cout', '<i4'), ('Cin', '<i4'),
                                                          ('variant', '<i4'), ('dgrad', '<i4'), ('col0', '<i4'), ('np', '<i4')]))
             offs, total, col = [], 0, 0
@@ -128,10 +143,21 @@ class _Workspace:
                 desc['packed'][i] = store.data_ptr() + o
             table = torch.from_numpy(desc.view(np.uint8).copy()).to(self.device)
             views = [store[o:o + n].view(torch.float32) for o, n in offs]
-            cache = self._packs = (sig, table, store, views, col)
+            cache = caches[sig] = (sig, table, store, views, col)
         _, table, _, views, col = cache
         call('mmlf_pack_filters_h2', ptr(table), len(items), col, _lib.stream_ptr())
         return {key: v for (key, _, _, _), v in zip(items, views)}
+
+    def enter_stream(self):
+        """Called where a workspace-owned buffer is about to be overwritten: if the calling thread has moved to another
+        stream since this workspace was last used, that stream waits for the work the previous one had enqueued."""
+        if self.device.type != 'cuda':
+            return
+        cur = torch.cuda.current_stream(self.device)
+        last = self.__dict__.get('_last_stream')
+        if last is not None and last != cur:
+            cur.wait_event(last.record_event())
+        self._last_stream = cur
 
     def scratch(self, name, n):
         """a float32 scratch buffer of at least n elements, reused across calls of this thread on this stream"""

@@ -74,13 +74,22 @@ def multimodal_mask(mpi, threshhold=0.3):
     return ((mpi[:, :, 3] > threshhold).sum(1) > 1).double()
 
 
-def kl_divergence(dist, dist_gt, mask=None):
-    """validate/cli.py:174-187 (batch size 1, as in validate).  Does not modify its inputs."""
+def kl_divergence(dist, dist_gt, mask=None, inplace=False):
+    """validate/cli.py:174-187 (batch size 1, as in validate).  The reference's helper smooths and renormalises ITS
+    ARGUMENTS in place (`dist += epsilon; dist /= np.sum(dist, 1)`), and the loop that calls it three times in a row
+    (validate/cli.py:333-335) passes the same arrays each time: `inplace=True` does the same to the tensors passed in
+    (in their own dtype, as numpy does), `inplace=False` leaves them untouched."""
     eps = 0.00001
-    dist = dist + eps
-    dist_gt = dist_gt + eps
-    dist = dist / dist.sum(1, keepdim=True)
-    dist_gt = dist_gt / dist_gt.sum(1, keepdim=True)
+    if inplace:
+        dist.add_(eps)
+        dist_gt.add_(eps)
+        dist.div_(dist.sum(1, keepdim=True))
+        dist_gt.div_(dist_gt.sum(1, keepdim=True))
+    else:
+        dist = dist + eps
+        dist_gt = dist_gt + eps
+        dist = dist / dist.sum(1, keepdim=True)
+        dist_gt = dist_gt / dist_gt.sum(1, keepdim=True)
     kld = (dist_gt * torch.log(dist_gt / dist)).sum(1)
     if mask is None:
         return kld.mean()
@@ -99,14 +108,22 @@ def nll_laplace(mpi, mean, logvar, mask=None):
     return nllh.mean()
 
 
-def nll_discrete(weights, posterior, vmin=None, vmax=None, mask=None):
+def nll_discrete(weights, posterior, vmin=None, vmax=None, mask=None, inplace=False):
     """validate/cli.py:52-73: negative log likelihood of the multi-plane target under a discrete posterior (the 7.0 is
-    the reference's bin-width constant).  Does not modify its inputs."""
+    the reference's bin-width constant).  Like `kl_divergence`, the reference's helper rewrites its arguments in place
+    (`posterior += epsilon; posterior /= np.sum(posterior, 1) * 7.0`) -- and for --model_discrete the loop's `dist` IS that
+    `posterior` array (validate/cli.py:321): `inplace=True` reproduces it, `inplace=False` leaves the inputs untouched."""
     eps = 0.00001
-    weights = _f64(weights) + eps
-    posterior = posterior + eps                      # the reference keeps the model's float32 here
-    weights = weights / weights.sum(1, keepdim=True)
-    posterior = posterior / (posterior.sum(1, keepdim=True) * 7.0)
+    if inplace:
+        weights.add_(eps)
+        posterior.add_(eps)
+        weights.div_(weights.sum(1, keepdim=True))
+        posterior.div_(posterior.sum(1, keepdim=True) * 7.0)
+    else:
+        weights = _f64(weights) + eps
+        posterior = posterior + eps                      # the reference keeps the model's float32 here
+        weights = weights / weights.sum(1, keepdim=True)
+        posterior = posterior / (posterior.sum(1, keepdim=True) * 7.0)
     nllh = (weights * -torch.log(posterior)).sum(1)
     if mask is not None:
         return (nllh * mask).sum() / mask.sum()

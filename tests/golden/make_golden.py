@@ -541,6 +541,27 @@ def g10_validate():
             rec[f'{k}/kld'] = np.float64(vcli.kl_divergence(dist.copy(), dist_gt.copy()))
             rec[f'{k}/kld_mm'] = np.float64(vcli.kl_divergence(dist.copy(), dist_gt.copy(), mm))
             rec[f'{k}/kld_um'] = np.float64(vcli.kl_divergence(dist.copy(), dist_gt.copy(), 1.0 - mm))
+        # what the LOOP prints (validate/cli.py:313-337): the helpers rewrite their arguments in place and the loop hands
+        # the same arrays to nll_discrete and to three kl_divergence calls in a row -- replayed here without copies
+        for k in ('base', 'upr', 'dpp', 'ese'):
+            d_gt = ref_dl.mpi_to_weights(torch.from_numpy(mpi), -3.5, 3.5, 108).cpu().numpy()
+            if k == 'ese':
+                dist, nll = vcli.lmm_to_discrete(108, -3.5, 3.5, means, np.exp(logvars)), 0.0
+            elif k == 'dpp':
+                post = posterior.copy()                       # the loop's `posterior`: the model output on the host
+                weights = ref_dl.mpi_to_weights(torch.from_numpy(mpi), -3.5, 3.5, 108).cpu().numpy()
+                dist = post
+                nll = vcli.nll_discrete(weights, post, -3.5, 3.5, None)
+            elif k == 'upr':
+                dist = vcli.laplace_to_discrete(108, -3.5, 3.5, mean, logvar)
+                nll = vcli.nll_laplace(mpi, mean, logvar, None)
+            else:
+                nll = vcli.nll_laplace(mpi, mean, np.zeros_like(mean), None)
+                dist = vcli.mean_to_discrete(108, -3.5, 3.5, mean)
+            rec[f'{k}/seq_nll'] = np.float64(nll)
+            rec[f'{k}/seq_kld'] = np.float64(vcli.kl_divergence(dist, d_gt))
+            rec[f'{k}/seq_kld_mm'] = np.float64(vcli.kl_divergence(dist, d_gt, mm))
+            rec[f'{k}/seq_kld_um'] = np.float64(vcli.kl_divergence(dist, d_gt, 1.0 - mm))
     np.savez_compressed(os.path.join(HERE, 'g10_validate.npz'), **rec)
     print('G10 validate', {k: float(v) for k, v in rec.items() if '/' in k})
 

@@ -121,7 +121,7 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--global-batch', '8',
-           '--patch', '32', '--steps', '1', '--warmup', '1', '--backend', 'gloo', '--no-cpu-baseline', '--no-f32-leg']
+           '--patch', '32', '--steps', '1', '--warmup', '1', '--backend', 'gloo', '--no-cpu-baseline', '--no-f32-leg', '--ese-size', '48']
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
@@ -130,3 +130,7 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     assert line['n_gpus'] == 2 and line['config']['per_gpu_batch'] == 4 and line['config']['parallelism'] == 'dp2'
     assert line['scaling'] == 'strong' and line['value'] > 0 and np.isfinite(line['config']['loss'])
     assert 'gloo' in line['config']['backend']
+    # BASELINE.json configs[4] under --gpus N: one light field per rank, replicas only, slowest rank reported
+    rep = line['ese_replicas']
+    assert rep['scenes'] == 2 and rep['members'] == 70 and rep['finite'] and rep['value'] > 0
+    assert abs(rep['scenes_per_s'] - 2 / rep['value']) < 1e-2 * rep['scenes_per_s']

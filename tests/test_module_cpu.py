@@ -111,6 +111,8 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mmlf_abi_version() == _lib.ABI_VERSION
+    # one number, one place: the header's macro is what the library returns and what the binding checks
+    macro = int(re.search(r'^#define\s+MMLF_ABI_VERSION\s+(\d+)', header, re.M).group(1))
+    assert lib.mmlf_abi_version() == _lib.ABI_VERSION == macro
     lib.mmlf_grid_alloc_positions.restype = ctypes.c_int64
     assert lib.mmlf_grid_alloc_positions(2, 96, 96) >= 2 * 98 * 98 + 99

@@ -130,11 +130,15 @@ class _StubModel(torch.nn.Module):
 
 
 @pytest.mark.parametrize('dev', DEVICES)
+@pytest.mark.parametrize('compat', [True, False])
 @pytest.mark.parametrize('kind', ['base', 'upr', 'dpp', 'ese'])
-def test_validation_loop_vs_reference_helpers(kind, dev, tmp_path):
+def test_validation_loop_vs_reference_helpers(kind, compat, dev, tmp_path):
     """reference validate/cli.py:249-351 per scene: MSE / BadPix (15-px margin), discretised predictive distribution,
     KL divergences over all / multimodal / unimodal pixels, NLL -- golden from the reference's own helper functions on
-    fixed head outputs (tests/golden/g10_validate.npz) -- and the result files it writes"""
+    fixed head outputs (tests/golden/g10_validate.npz) -- and the result files it writes.  compat=True: the numbers the
+    reference's LOOP prints (its helpers rewrite their arguments in place and the loop passes the same arrays to
+    nll_discrete and to three kl_divergence calls, validate/cli.py:313-337: golden keys `seq_*`, replayed without
+    copies); compat=False: every metric from freshly discretised distributions (golden keys without `seq_`)."""
     from mmlf_amd import pfm, validate
     g = load_golden('g10_validate.npz')
     t = lambda k: torch.from_numpy(g[k]).to(dev)
@@ -148,12 +152,18 @@ def test_validation_loop_vs_reference_helpers(kind, dev, tmp_path):
     H, W = g['gt'].shape[1:]
     views = [torch.rand(1, 3, 3, H, W) for _ in range(4)]
     scene = (*views, torch.rand(1, 3, H, W), t('gt'), t('mpi'), None, torch.tensor([[1]]))
-    rows, avg = validate.validate_scenes(_StubModel(out), [scene], out_dir=str(tmp_path), scene_names=['a', 'b'])
+    before = {k: v.clone() for k, v in out.items() if v is not None}
+    rows, avg = validate.validate_scenes(_StubModel(out), [scene], out_dir=str(tmp_path), scene_names=['a', 'b'],
+                                         reference_compat=compat)
     assert len(rows) == 1
+    for k, v in before.items():                     # the in-place replay works on copies: the model's outputs are untouched
+        assert torch.equal(out[k], v), k
     np.testing.assert_allclose(avg['mse'], g['mse'], rtol=1e-5)
     np.testing.assert_allclose(avg['badpix'], g['badpix'], rtol=1e-6)
     for key in ('kld', 'kld_mm', 'kld_um', 'nll'):
-        np.testing.assert_allclose(avg[key], g[f'{kind}/{key}'], rtol=2e-5, atol=1e-9, err_msg=key)
+        np.testing.assert_allclose(avg[key], g[f'{kind}/{"seq_" if compat else ""}{key}'], rtol=2e-5, atol=1e-9, err_msg=key)
+    if kind == 'dpp':                               # the files hold the ORIGINAL posterior (the reference saves before it evaluates)
+        np.testing.assert_array_equal(np.load(str(tmp_path / 'scenes' / 'b' / 'posterior.npy')), g['posterior'][0])
     np.testing.assert_array_equal(pfm.load(str(tmp_path / 'scenes' / 'b' / 'result.pfm')), g['mean'][0][::-1])
     assert (tmp_path / 'ours' / 'runtimes' / 'b.txt').exists()
     if kind == 'ese':
