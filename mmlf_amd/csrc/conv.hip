@@ -89,6 +89,16 @@ __device__ __forceinline__ void mmlf_set_prio(int level)
 #ifndef MMLF_ABL_TERMS
 #define MMLF_ABL_TERMS 3     // cross terms of the f16 split that are evaluated (3 = the arithmetic; fewer: timing ablation)
 #endif
+// timing ablations that bracket a 64-position x 144-column wave layout before it is built (WRONG results):
+#ifndef MMLF_ABL_HALFB
+#define MMLF_ABL_HALFB 0       // 1: a wave reads the weight fragments of every second column block only (half the LDS reads)
+#endif
+#ifndef MMLF_ABL_DSPLIT
+#define MMLF_ABL_DSPLIT 0      // 1: the activation split is done twice per chunk (what two column halves per tile would cost)
+#endif
+#ifndef MMLF_ABL_NOEARLY
+#define MMLF_ABL_NOEARLY 0     // 1: no early barrier / next-chunk fragment prefetch (the registers a 4-row-block wave cannot spare)
+#endif
 #ifndef MMLF_RING16
 #define MMLF_RING16 3   // pipeline depth of the sixteen-wave conv variant (LDS: 30 KB per buffer + 20 KB; 4 measures the same)
 #endif
@@ -525,7 +535,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     // its last twelve MFMAs while they arrive -- the LDS latency of the chunk head (both waves of a SIMD stand in it at
     // once: 12 % of a 280-wide chunk by the wave's own clock) is off the critical path.  Needs G % 3 == 0 (the rotating
     // fragment slots line up across chunks) and enough column blocks behind the DMA issue for the pieces to land.
-    constexpr bool EARLY = PL == 2 && G % 3 == 0 && G >= 9;   // (the three-plane build has no registers to spare for it)
+    constexpr bool EARLY = !MMLF_ABL_NOEARLY && PL == 2 && G % 3 == 0 && G >= 9;   // (the three-plane build has no registers to spare for it)
     // A: [640 slots][channel half(2)] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
     // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
     // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
@@ -719,6 +729,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {ll[0], ll[1], ll[2], ll[3]};
             asp[mb][0] = __builtin_bit_cast(bf16x8, vh);
             asp[mb][PL - 1] = __builtin_bit_cast(bf16x8, vl);
+            if constexpr (MMLF_ABL_DSPLIT && PL == 2 && G == 18) {     // the same work once more, results discarded
+                float4 r0 = ra[mb][0], r1 = ra[mb][1];
+                asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
+                unsigned h2[4], l2[4];
+                split2_pair_f16(r0.x, r0.y, scale_a, h2[0], l2[0]);
+                split2_pair_f16(r0.z, r0.w, scale_a, h2[1], l2[1]);
+                split2_pair_f16(r1.x, r1.y, scale_a, h2[2], l2[2]);
+                split2_pair_f16(r1.z, r1.w, scale_a, h2[3], l2[3]);
+                asm volatile("" ::"v"(h2[0]), "v"(h2[1]), "v"(h2[2]), "v"(h2[3]), "v"(l2[0]), "v"(l2[1]), "v"(l2[2]), "v"(l2[3]));
+            }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -745,8 +765,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                 }
             }
             if (g + 2 < G) {
+                if (!(MMLF_ABL_HALFB && G == 18 && (g & 1))) {
 #pragma unroll
-                for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bp[pl * 4 * NP + 16 * (g + 2)];
+                    for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bp[pl * 4 * NP + 16 * (g + 2)];
+                }
             } else if (EARLY && !tile_end) {   // behind the barrier: the next chunk's first two column blocks (G % 3 == 0)
 #pragma unroll
                 for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bpn[pl * 4 * NP + 16 * (g + 2 - G)];
@@ -768,7 +790,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
 #define H2_TERM(pa, pb)                                                                                      \
     _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
         acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),          \
-                                                            __builtin_bit_cast(f16x8, bq[g % 3][pb]), acc[mb][g], 0, 0, 0)
+                                                            __builtin_bit_cast(f16x8, bq[(MMLF_ABL_HALFB && G == 18 && (g & 1) && g + 1 < G ? g + 1 : g) % 3][pb]), acc[mb][g], 0, 0, 0)
             if constexpr (PL == 3) {
                 X6_TERM(2, 0);
                 X6_TERM(0, 2);

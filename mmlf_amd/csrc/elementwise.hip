@@ -420,7 +420,12 @@ static inline int bn_rows_grid(int nrows, int cvn)
     return g < nrows ? g : nrows;
 }
 #ifndef MMLF_BN_ROWS_FIXED
-#define MMLF_BN_ROWS_FIXED 1     // 0: the first form (bn_rows_kernel), kept for A/B builds
+// 0 (default): bn_rows_kernel.  1: bn_rows_fixed_kernel -- round 4's A/B (profiles/r04_bn_bench_*.log, r04_ab_bench_bn.log):
+// stand-alone the two forms move the same bytes per second (apply 5.1 TB/s, backward apply 5.2-5.3 TB/s at 280 channels;
+// the device's own copy of the same tensor reaches 4.5-4.9 TB/s: a 1:1 read/write stream tops out there on this part,
+// reads alone reach 6.2-6.4), but INSIDE the training step the fixed form loses 1.2 % at bs=512 and 3 % at 64 patches
+// (1093-1098 vs 1108-1111 and 1000-1003 vs 1030-1041 patches/s, same box, interleaved runs).
+#define MMLF_BN_ROWS_FIXED 0
 #endif
 
 // NCHW <-> grid

@@ -73,7 +73,11 @@ class Ensamble(nn.Module):
 
     def forward(self, h_views, v_views, i_views=None, d_views=None):
         if i_views is None or d_views is None:
-            raise NotImplementedError('cross-only ensembles are outside the accelerated path')
+            # The reference's signature has the same defaults (ensamble.py:40), but its own loop cannot run without the
+            # diagonal stacks: it hands Shift a 2-tuple (ensamble.py:63-64) and Shift reads data[2] and data[3]
+            # unconditionally (hci4d.py:927-928) -- IndexError before the first member.  Same exception type here.
+            raise IndexError('Ensamble: i_views and d_views are required (the reference\'s Shift indexes data[2] and '
+                             'data[3] for a two-stack ensemble too, hci4d.py:927-928: list index out of range)')
         disps = self.members()
         S = len(disps)
         if h_views.is_cuda:

@@ -51,6 +51,21 @@ def test_ensamble_cpu_matches_reference():
     _check(out, g)
 
 
+def test_two_stack_ensemble_raises_like_the_reference():
+    """reference ensamble.py:40 declares i_views=None, d_views=None, but its loop hands Shift a 2-tuple (:63-64) and Shift
+    reads data[2] / data[3] unconditionally (hci4d.py:927-928): measured in the build container, the reference raises
+    `IndexError: list index out of range` before the first member.  Same exception type here, before any launch."""
+    from mmlf_amd.ensamble import Ensamble
+
+    class _Stub(torch.nn.Module):
+        def forward(self, *a):
+            raise AssertionError('the model must not be reached')
+
+    ens = Ensamble(_Stub(), -3.5, 3.5, 0.1)
+    with pytest.raises(IndexError):
+        ens(torch.rand(1, 9, 3, 8, 8), torch.rand(1, 9, 3, 8, 8))
+
+
 @pytest.mark.gpu
 def test_shift_hip_matches_reference():
     from mmlf_amd import _lib
