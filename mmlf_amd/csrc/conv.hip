@@ -96,6 +96,10 @@ __device__ __forceinline__ void mmlf_set_prio(int level)
 #ifndef MMLF_ABL_DSPLIT
 #define MMLF_ABL_DSPLIT 0      // 1: the activation split is done twice per chunk (what two column halves per tile would cost)
 #endif
+#ifndef MMLF_ABL_PRESPLIT
+#define MMLF_ABL_PRESPLIT 0    // 1: the activation operand arrives ALREADY split -- per position and 8-channel octet 16 bytes of f16
+#endif                         // `hi` then 16 bytes of `lo`, scale 2^10 (tools/presplit_bench.py makes such a tensor): what the wide
+                               // launches would take with producer-side splitting; results are correct for such input
 #ifndef MMLF_ABL_NOEARLY
 #define MMLF_ABL_NOEARLY 0     // 1: no early barrier / next-chunk fragment prefetch (the registers a 4-row-block wave cannot spare)
 #endif
@@ -656,6 +660,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     float scale_a = 1.f, unscale_a = 1.f, run_max = 0.f;
     if constexpr (PL == 2) {
         scale_a = wave_operand_scale(wave_operand_amax_gather(late_args(), (long long)tile * TILE, w, lane));
+        if (MMLF_ABL_PRESPLIT && G == 18) scale_a = 1024.f;
         unscale_a = 1.f / scale_a;
     }
 #pragma unroll
@@ -720,6 +725,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                 split3_pair(ra[mb][1].z, ra[mb][1].w, hh[3], mm[3], ll[3]);
                 const u32x4_t vm = {mm[0], mm[1], mm[2], mm[3]};
                 asp[mb][1] = __builtin_bit_cast(bf16x8, vm);
+            } else if constexpr (MMLF_ABL_PRESPLIT && G == 18) {
+                hh[0] = __float_as_uint(ra[mb][0].x); hh[1] = __float_as_uint(ra[mb][0].y);
+                hh[2] = __float_as_uint(ra[mb][0].z); hh[3] = __float_as_uint(ra[mb][0].w);
+                ll[0] = __float_as_uint(ra[mb][1].x); ll[1] = __float_as_uint(ra[mb][1].y);
+                ll[2] = __float_as_uint(ra[mb][1].z); ll[3] = __float_as_uint(ra[mb][1].w);
             } else {
                 split2_pair_f16(ra[mb][0].x, ra[mb][0].y, scale_a, hh[0], ll[0]);
                 split2_pair_f16(ra[mb][0].z, ra[mb][0].w, scale_a, hh[1], ll[1]);
@@ -832,6 +842,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             if constexpr (PL == 2) {
                 if (tile < ntiles) {
                     scale_a = wave_operand_scale(next_amax);
+                    if (MMLF_ABL_PRESPLIT && G == 18) scale_a = 1024.f;
                     unscale_a = 1.f / scale_a;
                 }
             }

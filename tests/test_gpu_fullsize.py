@@ -115,18 +115,54 @@ def test_train_step_gradients_bs128_vs_stock_torch_autograd():
         assert float((got - ref).norm()) <= 3e-2 * float(ref.norm()) + floor, n
 
 
+class _ChunkedConv(torch.autograd.Function):
+    """nn.Conv2d's arithmetic (stock torch / MIOpen kernels) evaluated in batch chunks of 128 -- a convolution is
+    independent per sample, its weight gradient a sum over samples (summed here in float64).  Needed because the stock
+    FULL-BATCH weight gradient is wrong at this size on this stack: for one 280->280 layer on a (512, 280, 96, 96) input
+    (5.3 GB) `torch` (2.10.0+rocm7.0, MIOpen) returns a weight gradient 99.5 % (relative L2) away from the sum of its own four
+    128-sample chunks, while this library's kernels agree with that sum to 1e-5 (tools/miopen_wgrad_bs512.py,
+    profiles/r04_miopen_wgrad_bs512.log).  The reference never meets this: its DataParallel puts 64 patches on a GPU."""
+    CH = 128
+
+    @staticmethod
+    def forward(ctx, x, w, b, pad):
+        ctx.save_for_backward(x, w)
+        ctx.pad = pad
+        return torch.cat([torch.nn.functional.conv2d(x[s:s + _ChunkedConv.CH], w, b, padding=pad)
+                          for s in range(0, x.shape[0], _ChunkedConv.CH)])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        pad, CH = ctx.pad, _ChunkedConv.CH
+        gx = torch.cat([torch.nn.grad.conv2d_input(x[s:s + CH].shape, w, gy[s:s + CH], padding=pad)
+                        for s in range(0, x.shape[0], CH)])
+        gw = torch.zeros(w.shape, dtype=torch.float64, device=w.device)
+        for s in range(0, x.shape[0], CH):
+            gw += torch.nn.grad.conv2d_weight(x[s:s + CH], w.shape, gy[s:s + CH], padding=pad).double()
+        return gx, gw.float(), gy.sum((0, 2, 3)), None
+
+
 def _torch_forward_checkpointed(m, h, v, i, d):
-    """reference mmlf/model/feed_forward.py:226-269 on the module tree with stock torch ops, every
-    conv-ReLU-conv-BN-ReLU block under torch.utils.checkpoint: only block inputs stay alive for backward (about
-    60 GB at bs=512 instead of the 170 GB plain autograd saves), each block is recomputed when its gradient is due.
-    Train-mode BatchNorm normalises with the batch statistics in both passes, so the gradients are those of the plain
-    graph (the running statistics are updated twice; they are not compared here)."""
+    """reference mmlf/model/feed_forward.py:226-269 on the module tree with stock torch ops (convolutions through
+    _ChunkedConv, BatchNorm / ReLU on the full batch), every conv-ReLU-conv-BN-ReLU block under torch.utils.checkpoint:
+    only block inputs stay alive for backward (about 60 GB at bs=512 instead of the 170 GB plain autograd saves), each
+    block is recomputed when its gradient is due.  Train-mode BatchNorm normalises with the batch statistics in both
+    passes, so the gradients are those of the plain graph (the running statistics are updated twice; not compared)."""
     from torch.utils.checkpoint import checkpoint
     b, n, c, hh, ww = h.shape
 
+    def block_fwd(block, x):
+        for layer in block:
+            if isinstance(layer, torch.nn.Conv2d):
+                x = _ChunkedConv.apply(x, layer.weight, layer.bias, layer.padding[0])
+            else:
+                x = layer(x)
+        return x
+
     def run(net, x):
         for block in net:
-            x = checkpoint(block, x, use_reentrant=False)
+            x = checkpoint(block_fwd, block, x, use_reentrant=False)
         return x
 
     h, v = h.view(b, n * c, hh, ww), v.view(b, n * c, hh, ww)
@@ -139,8 +175,9 @@ def _torch_forward_checkpointed(m, h, v, i, d):
 def test_train_step_gradients_bs512_vs_stock_torch_autograd():
     """BASELINE.json's own batch: full-width fwd + loss + bwd at 512 patches, every parameter gradient of the native
     path against stock torch ops + autograd on the same GPU (what the reference executes), the reference side run
-    block-checkpointed so that it fits beside nothing else (plain autograd saves 170 GB at this size and stops at
-    bs=128, the test above).  Same bar as there: end-to-end gradients are ill-conditioned."""
+    block-checkpointed so that it fits (plain autograd saves 170 GB at this size and stops at bs=128, the test above) and
+    with its convolutions in 128-sample chunks (the stock full-batch weight gradient is wrong at this size: _ChunkedConv).
+    Same bar as there: end-to-end gradients are ill-conditioned."""
     from mmlf_amd import loss
     kw = dict(BASE_KW, model_uncert=True)
     stacks, gt = _inputs(512, 5)
@@ -169,15 +206,16 @@ def test_train_step_gradients_bs512_vs_stock_torch_autograd():
     np.testing.assert_allclose(grads['native'][0], grads['torch'][0], rtol=1e-4)
     assert float((grads['native'][2] - grads['torch'][2]).abs().mean()) <= DEPTH_MAE_TOL
     floor = 1e-4 * max(float(g.norm()) for g in grads['torch'][1].values())
-    worst = 0.0
+    worst = (0.0, None)
     for n, ref in grads['torch'][1].items():
         if n.endswith('.2.bias') and not n.startswith('out_net.7.'):
             continue        # conv bias in front of BatchNorm: true-zero gradient, noise on both paths
         got = grads['native'][1][n]
-        rel = float((got - ref).norm()) / (float(ref.norm()) + floor)
-        worst = max(worst, rel)
-        assert float((got - ref).norm()) <= 3e-2 * float(ref.norm()) + floor, (n, rel)
-    print(f'bs=512 gradients vs stock torch autograd: worst tensor {worst:.4f} relative L2')
+        rel = float((got - ref).norm()) / (float(ref.norm()) + floor / 3e-2)
+        if rel > worst[0]:
+            worst = (rel, n)
+    print(f'bs=512 gradients vs stock torch autograd (chunked convolutions): worst tensor {worst[1]} {worst[0]:.4f} relative L2')
+    assert worst[0] <= 2e-2, worst          # measured 1.1 % (in_net_id.1.2.weight); the 3 % of the bs=128 test absorbs a head flip
 
 
 @pytest.mark.parametrize('C', [280, 70])

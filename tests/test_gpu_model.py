@@ -9,6 +9,12 @@ from conftest import BASE_KW, TINY_KW, VARIANTS, load_golden
 from mmlf_amd import synth
 
 pytestmark = pytest.mark.gpu
+# G2 gradient bars, relative L2 per parameter tensor against the reference's float32 run.  End-to-end gradients are
+# ill-conditioned: the reference's own float32 and float64 runs differ by 0.6-0.9 % per tensor.  The BASE
+# input additionally has ONE head unit whose ReLU flips between implementations (tools/mode_diverge.py): +1.6-1.9 % on every
+# tensor below the head; measured worst tensors 2.44 % (in_net_id.1.3.weight), median 1.7 %.  UPR / DPP have no such unit:
+# worst 0.98 % / 1.08 % (in_net_id.2.3.bias / in_net_hv.1.0.bias), medians 0.7 % / 0.9 %.  (Round 3 used 3 % for all.)
+G2_GRAD_BAR = {'base': 2.6e-2, 'upr': 1.2e-2, 'dpp': 1.3e-2}
 DEPTH_MAE_TOL = 1e-4
 
 
@@ -135,13 +141,18 @@ def test_g2_full_size_train_step_vs_reference(variant):
     np.testing.assert_allclose(loss.item(), g['loss'], rtol=1e-4)
     loss.backward()
     # end-to-end gradients are ill-conditioned (the reference's own fp32 vs fp64 runs differ by 0.6 % here, and this
-    # input has a head unit whose ReLU flips between implementations: +1.6 %): 3 % relative L2 per tensor is the bar
+    # input has a head unit whose ReLU flips between implementations: +1.6 %): G2_GRAD_BAR per variant is the bar
     # HERE; test_conditioned_train_step_gradients_at_float32_level holds the tight one
+    ratios = {}
     for n, p in m.named_parameters():
         ref = g[f'grad_s/{n}']
         got = p.grad.cpu().numpy()
         got = got.reshape(-1)[::97] if got.size > 4096 else got
-        assert np.linalg.norm(got - ref) <= 3e-2 * np.linalg.norm(ref) + 5e-6, n   # floor: biases feeding BN have zero true gradient
+        ratios[n] = np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 5e-6 / 3e-2)   # floor: biases feeding BN have zero true gradient
+    worst = sorted(ratios.items(), key=lambda kv: -kv[1])[:3]
+    print(f'G2 {variant}: gradient relative L2 per tensor: median {np.median(list(ratios.values())):.4f}, worst {worst}')
+    for n, r in ratios.items():
+        assert r <= G2_GRAD_BAR[variant], (n, r)
     for k, v in m.state_dict().items():
         if 'running' in k:
             np.testing.assert_allclose(v.cpu().numpy(), g[f'post/{k}'], rtol=5e-5, atol=2e-6, err_msg=k)
@@ -152,8 +163,8 @@ def test_g2_full_size_train_step_vs_reference(variant):
 def test_conditioned_train_step_gradients_at_float32_level(variant, mode, monkeypatch):
     """How far may a float32 implementation's gradients be from the truth?  The gradient of this net is discontinuous
     where few units carry much of it: ONE ReLU flip in the head's one-channel first convolution (a pre-activation
-    within rounding noise of zero) moves every gradient below it by 1.6 % -- that, not arithmetic, is what the 3 %
-    bar of the G2 test above absorbs (measured: tools/mode_diverge.py finds exactly one such unit in G2's input).
+    within rounding noise of zero) moves every gradient below it by 1.6 % -- that, not arithmetic, is what the 2.6 %
+    BASE bar of the G2 test above absorbs (measured: tools/mode_diverge.py finds exactly one such unit in G2's input).
     tests/golden/g11_conditioned_*.npz is a train step whose head pre-activations and L1 signs all stay 1e-4 (20 x the
     noise) away from flipping, with the reference's float32 AND float64 runs.  Yardstick = the reference's own float32
     distance from its float64 run, per parameter tensor.  On this fixture torch's own GPU kernels (MIOpen / ATen, the
