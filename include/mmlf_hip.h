@@ -41,7 +41,7 @@ const char *mmlf_last_error(void);
 /* Bumped whenever an entry point's arguments or a layout they share changes.  mmlf_abi_version() returns the value the
  * library was BUILT with: a binding compares it with the header it was written against (mmlf_amd/_lib.py does, and reads
  * the number from this line) before making any other call. */
-#define MMLF_ABI_VERSION 4
+#define MMLF_ABI_VERSION 5
 int mmlf_abi_version(void);
 
 /* number of positions a grid buffer must provide for batch B and image extent H x W */
@@ -123,8 +123,8 @@ int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const
  * this launch; relu_mask_in -- the mask a launch with the same (B,H,W) and N wrote -- replaces relu_ref in the data
  * gradient (nn.ReLU backward, feed_forward.py:124): the layer's activations are not read again. */
 int64_t mmlf_relu_mask_words(int B, int H, int W);
-/* number of workgroups mmlf_conv2x2_h2 launches for this shape (= rows of bn_partial) */
-int mmlf_conv2x2_blocks(int N, int B, int H, int W);
+/* number of workgroups mmlf_conv2x2_h2 launches for K input and N output channels on this grid (= rows of bn_partial) */
+int mmlf_conv2x2_blocks(int K, int N, int B, int H, int W);
 
 /* "Thin" convolution: N <= 2 output channels over a wide input (first convolution of the BASE / UPR head,
  * feed_forward.py:179-182): a matrix-vector product bound by reading the input once, evaluated with plain float32

@@ -39,7 +39,7 @@ SIGNATURES = {
     'mmlf_conv2x2_thin': (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mmlf_conv2x2_wgrad_thin_workspace_floats': (_i64, [_i]),
     'mmlf_conv2x2_wgrad_thin': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
-    'mmlf_conv2x2_blocks': (_i, [_i, _i, _i, _i]),
+    'mmlf_conv2x2_blocks': (_i, [_i, _i, _i, _i, _i]),
     'mmlf_bn_stats_finalize': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mmlf_conv2x2_wgrad': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     'mmlf_conv2x2_wgrad_split': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp]),

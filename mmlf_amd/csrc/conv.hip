@@ -880,6 +880,171 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
 
 
 
+// ---------------------------------------------------------------------------------------------
+// Narrow layers, f16 split, round 4: conv4tap_rs_kernel -- "register-streamed".  The stream layers (27 -> 70, 70 -> 70:
+// reference feed_forward.py:139-157) have K = 4 x 72 at most and 80 packed columns: 30 MFMAs per wave and 8-channel
+// chunk, against which the tiled kernel's per-chunk costs (barrier, chunk head, DMA wait: half of its time by the wave's
+// own clock) do not amortise, and whose 355- / 611-position windows come from HBM 1.4-1.5 times.  Here
+//  * the WHOLE packed filter (NCH x 10 KB, 92 KB at 72 channels) is copied into LDS once per workgroup and stays;
+//  * a wave owns a 32-position group at a time, end to end: every lane loads the full channel row of its (position, tap)
+//    straight into registers -- 2 x NCH 16-byte loads per row block, consecutive bytes per lane, issued in one burst so
+//    that a 128-byte line is touched by eight back-to-back instructions -- multiplies, runs the common epilogue, moves on;
+//  * no LDS traffic for activations, no DMA, NO barrier in the loop: the two waves of a SIMD drift apart by themselves,
+//    one multiplies while the other waits for its loads and stores (counted vmcnt waits per chunk: loads return in order);
+//  * groups are dealt so that the waves of one XCD work on neighbouring groups at any time: the row a group reads as
+//    taps 2, 3 is the row three groups further on read as taps 0, 1 -- an L2 hit instead of a second HBM read.
+// Layouts (mask words, statistics, amax, scales) are indexed by the global 32-position group exactly as in
+// conv4tap_x6s_kernel (tile = group / 8, wave = group % 8): the two kernels write the same bytes.
+// ---------------------------------------------------------------------------------------------
+template <int G, int NCH, int EPI>
+__global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngroups)
+{
+    constexpr int NP = G * 16;
+    constexpr int WBYTES = NCH * 2 * 4 * NP * 16;            // [chunk][plane][tap][NP][8 f16]
+    // K order.  A "full" MFMA step is ONE tap x 32 channels: lane quarter q4 carries channel octet q4 of the step, so the
+    // four lanes of a position read 128 consecutive bytes of its row (one or two cache lines per position and
+    // instruction; with quarter = tap, as in the tiled kernel's LDS image, every lane of a load instruction sits in
+    // another line and the L1 tag rate, one line per clock, made the loads cost as much as a full HBM stream).  The
+    // channels left over (NCH % 4 == 1: 64..71 of 72) form one last step in the quarter = tap layout.  The packed filter
+    // needs no other layout: a lane's fragment of step (tap t, octets 4s .. 4s+3) is chunk 4s + q4 of tap t.
+    constexpr int NS = NCH / 4, REM = NCH % 4;
+    static_assert(REM == 0 || REM == 1, "input channels: a multiple of 32, or one octet more");
+    constexpr int NSTEP = 4 * NS + REM, NLOAD = 4 * NSTEP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q4 = lane >> 4;
+
+    for (int o = tid * 16; o < WBYTES; o += 512 * 16)
+        *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.wp) + o);
+    double *stats_all = reinterpret_cast<double *>(smem + WBYTES);            // [8 waves][NP][2]
+    if (a.bn_partial)
+        for (int k = tid; k < 8 * NP * 2; k += 512) stats_all[k] = 0.0;
+    __syncthreads();
+
+    // this wave's groups: XCD x (blocks b with b % 8 == x share it) takes the contiguous range [x * per, (x + 1) * per);
+    // inside it the XCD's waves stride together
+    int gi, gstep, gend;
+    if ((gridDim.x & 7) == 0) {
+        const int per = (ngroups + 7) >> 3, nbx = (int)gridDim.x >> 3;
+        const int x = (int)blockIdx.x & 7;
+        gi = x * per + ((int)blockIdx.x >> 3) * 8 + w;
+        gstep = nbx * 8;
+        gend = min(ngroups, (x + 1) * per);
+    } else {
+        gi = (int)blockIdx.x * 8 + w;
+        gstep = (int)gridDim.x * 8;
+        gend = ngroups;
+    }
+
+    f32x4 acc[2][G];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < G; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
+    float run_max = 0.f;
+    const bf16x8 *bpF = reinterpret_cast<const bf16x8 *>(smem) + q4 * 8 * NP + r16;   // full steps: + (8 s + pl) * 4 NP + t NP + 16 nb
+    const bf16x8 *bpR = reinterpret_cast<const bf16x8 *>(smem) + q4 * NP + r16;       // last step:  + (8 NS + pl) * 4 NP + 16 nb
+    auto bfrag = [&](int k, int nb, int pl) -> bf16x8 {        // k, nb, pl are compile-time after unrolling
+        return k < 4 * NS ? bpF[(8 * (k % NS) + pl) * 4 * NP + (k / NS) * NP + 16 * nb] : bpR[(8 * NS + pl) * 4 * NP + 16 * nb];
+    };
+    const size_t row_off = (size_t)r16 * a.cs_in;                                     // floats
+    const size_t rem_off = (size_t)((q4 & 1) + (q4 >> 1) * a.P) * a.cs_in + 32 * NS;
+
+    for (; gi < gend; gi += gstep) {
+        const long long Q0 = (long long)(gi >> 3) * MMLF_TILE;
+        const int wv = gi & 7;
+        // row maxima first (their loads are the oldest: the first counted wait below covers them)
+        const float gathered = wave_operand_amax_gather(a, Q0, wv, lane);
+        const float *p0 = a.in + (size_t)(Q0 + 32 * wv) * a.cs_in + row_off;
+        float4 raw[NSTEP][2][2];                                   // [step][row block][half]
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {
+            const int t = k / NS, s_ = k % NS;                         // (full steps)
+            const float *pk = k < 4 * NS ? p0 + (size_t)((t & 1) + (t >> 1) * a.P) * a.cs_in + 32 * s_ + 8 * q4 : p0 + rem_off;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    raw[k][mb][hf] = reinterpret_cast<const float4 *>(pk + (size_t)(16 * mb) * a.cs_in)[hf];
+            __builtin_amdgcn_sched_barrier(0);          // step order: the counted waits below rely on it
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD > 63 ? 63 : NLOAD) : "memory");
+        const float scale_a = wave_operand_scale(gathered);
+        const float unscale_a = 1.f / scale_a;
+        bf16x8 bq[3][2];
+#pragma unroll
+        for (int g0 = 0; g0 < 2; ++g0)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) bq[g0][pl] = bfrag(0, g0, pl);
+#pragma unroll
+        for (int k = 0; k < NSTEP; ++k) {
+            // loads come back in order: step k's four are done once at most 4 (NSTEP - 1 - k) younger ones are outstanding
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTEP - 1 - k) > 63 ? 63 : 4 * (NSTEP - 1 - k)) : "memory");
+            bf16x8 asp[2][2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                unsigned hh[4], ll[4];
+                float4 &r0 = raw[k][mb][0], &r1 = raw[k][mb][1];
+                asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
+                split2_pair_f16(r0.x, r0.y, scale_a, hh[0], ll[0]);
+                split2_pair_f16(r0.z, r0.w, scale_a, hh[1], ll[1]);
+                split2_pair_f16(r1.x, r1.y, scale_a, hh[2], ll[2]);
+                split2_pair_f16(r1.z, r1.w, scale_a, hh[3], ll[3]);
+                const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {ll[0], ll[1], ll[2], ll[3]};
+                asp[mb][0] = __builtin_bit_cast(bf16x8, vh);
+                asp[mb][1] = __builtin_bit_cast(bf16x8, vl);
+            }
+            // The split is inline assembly: the compiler's hazard recognizer does not see a vector write in front of the
+            // matrix instruction that reads it (VALU write -> MFMA source read needs wait states), and its scheduler is
+            // free to put an MFMA between the two row blocks' splits.  Fenced on both sides: without the fences the nop
+            // moved up and column block 0 of whichever row block was split last came out with wrong low bits.
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 4" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                constexpr int NB = NSTEP * G;
+                const int idx = k * G + g;                      // block index in the (step, column block) stream
+                if (idx + 2 < NB) {
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) bq[(idx + 2) % 3][pl] = bfrag((idx + 2) / G, (idx + 2) % G, pl);
+                }
+#define RS_TERM(pa, pb)                                                                                      \
+    _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
+        acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),          \
+                                                            __builtin_bit_cast(f16x8, bq[idx % 3][pb]), acc[mb][g], 0, 0, 0)
+                RS_TERM(1, 0);
+                RS_TERM(0, 1);
+                RS_TERM(0, 0);
+#undef RS_TERM
+            }
+        }
+        conv_epilogue16<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max,
+                                a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < G; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
+    }
+    if (a.out_amax) mmlf_amax_update(run_max, a.out_amax);      // at most one atomic per wave per launch
+    if (a.bn_partial) {
+        __syncthreads();                                        // orders the waves' sums
+        for (int k = tid; k < 2 * a.n_true; k += 512) {
+            const int ch = k % a.n_true, which = k / a.n_true;
+            double t = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) t += stats_all[((size_t)ww * NP + ch) * 2 + which];
+            a.bn_partial[((size_t)blockIdx.x * 2 + which) * a.n_true + ch] = t;
+        }
+    }
+}
+
 // 512 threads = 8 waves; tile = 256 positions x NT*32 output channels; wave w owns positions
 // [32w, 32w+32) x all channels (NT accumulator tiles of 32x32).  K is walked in chunks of 8 input
 // channels x 4 taps, double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4: no
@@ -2076,11 +2241,68 @@ static int launch_conv_x6s_epi(const ConvArgs &a, long long ntiles, hipStream_t 
     return mmlf_launch_status(PL == 3 ? "mmlf_conv2x2_split" : "mmlf_conv2x2_h2");
 }
 
+// the register-streamed narrow kernel (conv4tap_rs_kernel) serves 80 packed columns over 4 or 9 input chunks (27 -> 70,
+// 70 -> 70) in the f16 split.
+// Where it runs (measured, profiles/r04_ab_bench_rs.log): on 96x96 training patches the two kernels take the same time
+// (0.94 ms per 70 -> 70 launch at bs=512 either way; whole step 1122-1127 patches/s both), so the tiled sixteen-wave
+// kernel keeps those launches; on pitches where that variant's 512 + P position window does not fit (full frames: the
+// 70 members of a 512x512 ESE scene) the tiled kernel falls back to eight waves and two window segments, and the
+// register-streamed kernel is 4.7 % faster end to end (0.436 vs 0.457 s per scene).  MMLF_CONV_RS=1 / 0 forces it on /
+// off for every eligible launch (A/B).
+static int conv_rs_mode()
+{
+    static const int mode = [] { const char *e = getenv("MMLF_CONV_RS"); return e ? atoi(e) : -1; }();
+    return mode;
+}
+static bool conv_rs_shape(int planes, int np, int nchunk, int nw)
+{
+    if (!(planes == 2 && np == 80 && (nchunk == 9 || nchunk == 4))) return false;
+    const int mode = conv_rs_mode();
+    return mode < 0 ? nw == 8 : mode != 0;
+}
+static long long conv_rs_blocks(long long ngroups)
+{
+    const long long grid = device_cus(), need = (ngroups + 7) / 8;
+    return grid > need ? need : grid;
+}
+template <int G, int NCH, int EPI>
+static int launch_conv_rs_epi(const ConvArgs &a, long long ngroups, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)NCH * 2 * 4 * (G * 16) * 16 + 8 * (G * 16) * 2 * sizeof(double);
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_rs_kernel<G, NCH, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL((conv4tap_rs_kernel<G, NCH, EPI>), dim3((unsigned)conv_rs_blocks(ngroups)), dim3(512), lds, st, a, (int)ngroups);
+    return mmlf_launch_status("mmlf_conv2x2_h2(register-streamed)");
+}
+template <int G, int NCH>
+static int launch_conv_rs(const ConvArgs &a, long long ngroups, hipStream_t st)
+{
+    const int kind = (a.relu ? EPI_RELU : 0) | (a.bn_partial ? EPI_STATS : 0) | (a.relu_mask_in ? EPI_BITS_IN : 0) |
+                     (a.ref ? EPI_REF_IN : 0) | (a.relu_mask_out ? EPI_MASK_OUT : 0);
+    switch (kind) {
+    case EPI_PLAIN: return launch_conv_rs_epi<G, NCH, EPI_PLAIN>(a, ngroups, st);
+    case EPI_RELU: return launch_conv_rs_epi<G, NCH, EPI_RELU>(a, ngroups, st);
+    case EPI_RELU | EPI_MASK_OUT: return launch_conv_rs_epi<G, NCH, EPI_RELU | EPI_MASK_OUT>(a, ngroups, st);
+    case EPI_STATS: return launch_conv_rs_epi<G, NCH, EPI_STATS>(a, ngroups, st);
+    case EPI_BITS_IN: return launch_conv_rs_epi<G, NCH, EPI_BITS_IN>(a, ngroups, st);
+    default: return launch_conv_rs_epi<G, NCH, EPI_GENERIC>(a, ngroups, st);
+    }
+}
+
 // the launch kinds of a training step get their own epilogue build on the hot shapes (f16 split, 70- and 280-wide
 // layers); every other combination of options runs the generic one
 template <int G, int PL>
 static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
+    if constexpr (PL == 2 && G == 5) {
+        if (conv_rs_shape(PL, G * 16, a.nchunk, a.nw)) {
+            const long long ngroups = ntiles * a.nw;            // 32-position groups of the padded grid
+            return a.nchunk == 9 ? launch_conv_rs<G, 9>(a, ngroups, st) : launch_conv_rs<G, 4>(a, ngroups, st);
+        }
+    }
     if constexpr (PL == 2 && (G == 5 || G == 18)) {
         const int kind = (a.relu ? EPI_RELU : 0) | (a.bn_partial ? EPI_STATS : 0) | (a.relu_mask_in ? EPI_BITS_IN : 0) |
                          (a.ref ? EPI_REF_IN : 0) | (a.relu_mask_out ? EPI_MASK_OUT : 0);
@@ -2214,12 +2436,13 @@ extern "C" int64_t mmlf_relu_mask_words(int B, int H, int W)
     return make_grid(B, H, W).NQpad / MMLF_TILE * 4096;        // [tile][8 waves][8 rows][64 lanes]
 }
 
-extern "C" int mmlf_conv2x2_blocks(int N, int B, int H, int W)
+extern "C" int mmlf_conv2x2_blocks(int K, int N, int B, int H, int W)
 {
     const int np = x6_np(N);
-    if (np < 0 || B <= 0 || H <= 0 || W <= 0) return -1;
+    if (np < 0 || K <= 0 || B <= 0 || H <= 0 || W <= 0) return -1;
     const Grid g = make_grid(B, H, W);
     const int nw = conv_sixteen_waves(2, np, g) ? 16 : 8;
+    if (conv_rs_shape(2, np, (K + 7) / 8, nw)) return (int)conv_rs_blocks(g.NQpad / 32);
     return (int)conv_split_blocks(np / 16, g.NQpad / (32 * nw), nw);
 }
 

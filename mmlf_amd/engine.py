@@ -410,7 +410,7 @@ class Trunk:
         rm, rv = p[f'{spec.prefix}.3.running_mean'], p[f'{spec.prefix}.3.running_var']
         if train:
             if fused_stats:
-                nblk = int(_lib.load().mmlf_conv2x2_blocks(cmid, B, H, W))
+                nblk = int(_lib.load().mmlf_conv2x2_blocks(cmid, cmid, B, H, W))
                 call('mmlf_bn_stats_finalize', ptr(ws.partial), nblk, C, ptr(g), ptr(bt), ptr(rm), ptr(rv),
                      self.momentum, self.eps, ptr(smean), ptr(sinv), ptr(scale), ptr(shift), B, H, W,
                      _lib.stream_ptr())

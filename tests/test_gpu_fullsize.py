@@ -239,7 +239,7 @@ def test_fused_batchnorm_statistics_bs512_vs_float64(C):
     z = geo.buf(cs, dev)
     ws = engine._Workspace.get(dev)
     engine.conv(geo, x, cs, C, engine.pack_filter(w, 0, False), bias, C, z, cs, geo.P + 1, H, W, False, bn_partial=ws.partial)
-    nblk = int(_lib.load().mmlf_conv2x2_blocks(C, B, H, W))
+    nblk = int(_lib.load().mmlf_conv2x2_blocks(C, C, B, H, W))
     c = torch.empty(4 * C, device=dev)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     call('mmlf_bn_stats_finalize', ptr(ws.partial), nblk, C, None, None, ptr(rm), ptr(rv), 1.0, 1e-5,

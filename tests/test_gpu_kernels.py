@@ -399,7 +399,7 @@ def test_fused_batchnorm_statistics_match_the_two_pass_form(cin, cout):
     call('mmlf_pack_filter_h2', ptr(w), ptr(pk), cout, cin, 0, 0, _lib.stream_ptr())
     amax = geo.amax_of(x, cs_in)
     z = geo.buf(cs_out, dev)
-    nblk = int(_lib.load().mmlf_conv2x2_blocks(cout, B, H, W))
+    nblk = int(_lib.load().mmlf_conv2x2_blocks(cin, cout, B, H, W))
     partial = torch.full((nblk * 2 * cout + 8,), float('nan'), dtype=torch.float64, device=dev)
     call('mmlf_conv2x2_h2', ptr(x), cs_in, cin, ptr(pk), ptr(bias), cout, ptr(z), cs_out, cs_out, geo.P + 1, H, W,
          B, H, W, 0, None, 0, ptr(amax), ptr(z.absmax), ptr(partial), None, None, _lib.stream_ptr())
@@ -530,10 +530,68 @@ def test_thin_convolution_and_weight_gradient(oracle, cin, cout, pad, variant):
     np.testing.assert_allclose(tgb.cpu().numpy() + 0.25, gb, rtol=1e-4, atol=2e-5 * np.abs(gb).max())
 
 
-def test_sixteen_wave_conv_variant_writes_the_same_bytes(tmp_path):
-    """The 512-position / sixteen-wave kernel of the 70-channel layers (small pitches) indexes masks, statistics and
-    scales by the global 32-position wave, so it must produce the same bytes as the eight-wave kernel: output, ReLU mask
-    words, row maxima and BatchNorm partial sums, compared across two processes (the switch is read once per process)."""
+@pytest.mark.parametrize('cin', [27, 70])
+@pytest.mark.parametrize('pad', [1, 0])
+def test_register_streamed_conv_on_wide_pitch(oracle, cin, pad):
+    """pitches above 127 positions (full frames: the 512x512 ESE scenes) send the 27 -> 70 and 70 -> 70 layers to
+    conv4tap_rs_kernel by default (the sixteen-wave tiled variant's window does not fit there); forward with bias and
+    ReLU, fused BatchNorm statistics and the ReLU bit mask against the oracle, everything outside the extent exactly zero"""
+    from mmlf_amd import engine, _lib
+    dev = _dev()
+    cout = 70
+    rs = np.random.RandomState(cin + pad)
+    B, H, W = 2, 5, 139          # pitch 141
+    geo = engine.Geometry(B, H, W)
+    assert geo.P > 127
+    w = rs.uniform(-0.5, 0.5, (cout, cin, 2, 2)).astype(np.float32)
+    b = rs.uniform(-0.5, 0.5, (cout,)).astype(np.float32)
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    if pad == 1:
+        x = rs.uniform(-1, 1, (B, cin, H, W)).astype(np.float32)
+        xg = grid_from_nchw(x, cs_in, geo, offset=1)
+        shift, vh, vw, oh, ow, ooff = 0, H + 1, W + 1, H + 1, W + 1, 0
+    else:
+        x = rs.uniform(-1, 1, (B, cin, H + 1, W + 1)).astype(np.float32)
+        xg = grid_from_nchw(x, cs_in, geo, offset=0)
+        shift, vh, vw, oh, ow, ooff = geo.P + 1, H, W, H, W, 1
+    tw, tb = torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
+    pk = engine.pack_filter(tw, 0, False)
+    xd = torch.from_numpy(xg).to(dev)
+    for relu in (False, True):
+        ref = oracle.conv2x2(x, w, b, pad, relu=relu)
+        out = geo.buf(cs_out, dev)
+        mask = torch.zeros_like(geo.relu_mask(dev)) if relu else None
+        ws = engine._Workspace.get(dev)
+        ws.partial.fill_(float('nan'))
+        engine.conv(geo, xd, cs_in, cin, pk, tb, cout, out, cs_out, shift, vh, vw, relu, mask_out=mask,
+                    bn_partial=None if relu else ws.partial)
+        got, g = nchw_from_grid(out.cpu().numpy(), cs_out, cout, geo, oh, ow, ooff)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+        g2 = g.copy()
+        g2[:, ooff:ooff + oh, ooff:ooff + ow, :cout] = 0
+        assert not g2.any()
+        true = geo.amax_of(out, cs_out)
+        assert float(out.absmax[0]) == float(true[0]) and bool((out.absmax >= true).all())
+        if relu:
+            bits = int(np.unpackbits(mask.cpu().numpy().view(np.uint8)).sum())
+            assert bits == int((got > 0).sum())                      # one bit per positive stored output
+        else:
+            nblk = int(_lib.load().mmlf_conv2x2_blocks(cin, cout, B, H, W))
+            part = ws.partial[:nblk * 2 * cout].view(nblk, 2, cout).sum(0).cpu().numpy()
+            assert np.isfinite(part).all()
+            np.testing.assert_allclose(part[0], ref.sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+            np.testing.assert_allclose(part[1], (ref.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), rtol=1e-4)
+
+
+def test_narrow_conv_kernel_variants_agree(tmp_path):
+    """The three kernels that can run a 70-channel layer: the tiled eight-wave kernel, its 512-position / sixteen-wave
+    variant, and the register-streamed kernel (round 4, the default: whole filter in LDS, activations global ->
+    registers, no barrier in the loop).  All index masks, statistics and scales by the global 32-position group.  The two
+    tiled kernels add every accumulator's products in the same order: same BYTES (output, ReLU mask words, row maxima,
+    masked data gradient; BatchNorm partial sums equal once summed over workgroups).  The register-streamed kernel walks
+    K tap by tap (32 channels of one tap per matrix instruction instead of 8 channels of four taps): the same sums in
+    another order -- equal to float32 rounding, mask bits equal except where an output is within rounding of zero.
+    Compared across processes (the switches are read once per process)."""
     import subprocess
     import sys
     script = r'''
@@ -558,7 +616,7 @@ engine.conv(geo, x, cs, cin, pk, b, cout, y, cs, 0, H + 1, W + 1, True, mask_out
 ws = engine._Workspace.get(dev)
 z = geo.buf(cs, dev)
 engine.conv(geo, y, cs, cout, pk, b, cout, z, cs, geo.P + 1, H, W, False, bn_partial=ws.partial)
-nblk = int(_lib.load().mmlf_conv2x2_blocks(cout, B, H, W))
+nblk = int(_lib.load().mmlf_conv2x2_blocks(cout, cout, B, H, W))
 part = ws.partial[:nblk * 2 * cout].double().view(nblk, 2, cout).sum(0)
 g = geo.buf(cs, dev)
 engine.conv(geo, z, cs, cout, engine.pack_filter(w, 0, True), None, cin, g, cs, 0, H + 1, W + 1, False, mask_in=mask)
@@ -567,16 +625,25 @@ np.savez(sys.argv[1], y=y.cpu().numpy(), z=z.cpu().numpy(), g=g.cpu().numpy(), m
          ay=y.absmax.cpu().numpy(), az=z.absmax.cpu().numpy(), part=part.cpu().numpy())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for nw in ('0', '1'):
-        out = str(tmp_path / f'nw{nw}.npz')
-        env = dict(os.environ, MMLF_CONV_NW16=nw)
+    for rs_on, nw in (('0', '0'), ('0', '1'), ('1', '1')):
+        out = str(tmp_path / f'rs{rs_on}_nw{nw}.npz')
+        env = dict(os.environ, MMLF_CONV_NW16=nw, MMLF_CONV_RS=rs_on)
         res = subprocess.run([sys.executable, '-c', script, out], env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(np.load(out))
+    a, b, c = outs
     for key in ('y', 'z', 'g', 'mask', 'ay', 'az'):
-        assert np.array_equal(outs[0][key], outs[1][key]), key
-    # the per-workgroup partial sums are grouped differently (256 vs 512 positions per workgroup): equal after the sum
-    np.testing.assert_allclose(outs[0]['part'], outs[1]['part'], rtol=1e-12)
+        assert np.array_equal(a[key], b[key]), key
+    # the per-workgroup partial sums are grouped differently (positions per workgroup differ): equal after the sum
+    np.testing.assert_allclose(a['part'], b['part'], rtol=1e-12)
+    for key in ('y', 'z', 'g'):
+        scale = np.abs(a[key]).max()
+        assert np.abs(a[key] - c[key]).max() <= 4e-6 * scale, (key, np.abs(a[key] - c[key]).max() / scale)
+    flips = np.unpackbits((a['mask'] ^ c['mask']).view(np.uint8)).sum() / (a['mask'].size * 32.0)
+    assert flips <= 1e-4, flips                       # (out > 0) of outputs within rounding of zero
+    np.testing.assert_allclose(a['ay'], c['ay'], rtol=2e-6)
+    np.testing.assert_allclose(a['az'], c['az'], rtol=2e-6)
+    np.testing.assert_allclose(a['part'], c['part'], rtol=1e-5, atol=1e-5 * np.abs(a['part']).max())
 
 
 def test_batched_filter_packing_and_slack_zeroing_equal_the_per_layer_calls():

@@ -476,7 +476,7 @@ def test_values_only_invalid_positions_read_cannot_poison_a_wave():
     keep, engine.CONV_MODE = engine.CONV_MODE, 'f16x3'
     try:
         pk = engine.pack_filter(wd, 0, False)
-        nblk = int(_lib.load().mmlf_conv2x2_blocks(cout, B, H, W))
+        nblk = int(_lib.load().mmlf_conv2x2_blocks(cin, cout, B, H, W))
         for relu in (False, True):
             z = geo.buf(cs, dev)
             partial = torch.full((nblk * 2 * cout + 8,), float('nan'), dtype=torch.float64, device=dev)
