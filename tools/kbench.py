@@ -75,5 +75,5 @@ def run(cin, cout):
         print(f'{TAG} {cin}->{cout} B={B} {k:14s} median {med:8.3f} ms  min {mn:8.3f} ms  {fl / med / 1e9:7.1f} TFLOP/s', flush=True)
 
 
-run(280, 280)
+if os.environ.get("KBENCH_ONLY70", "0") == "0": run(280, 280)
 if os.environ.get("KBENCH_ONLY280", "0") == "0": run(70, 70)
