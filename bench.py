@@ -268,6 +268,7 @@ def main():
     sync()
     dt = time.time() - t0
     prof, engine.PROFILE = engine.PROFILE, None
+    peak_gib = torch.cuda.max_memory_allocated(dev) / 2.0 ** 30        # this rank's peak of live tensors over warm-up + timed steps
     # further legs (N=1 only): the same step in the two arithmetic modes that carry no precision asterisk -- the exact-f32
     # MFMA kernels (5 steps) and the exact 3 x bf16 split (3 steps) -- same tensors, same shapes
     mode_legs = {}
@@ -354,6 +355,7 @@ def main():
                                    f'synthetic EPI patches, default torch init (BASELINE.json configs[1])',
                        'per_gpu_batch': B, 'parallelism': f'dp{world}', 'loss': round(loss_val, 6)},
             'whole_step_tflops': round(value * GFLOP_PER_PATCH[args.variant] / 1e3, 2),
+            'peak_hbm_gib': round(peak_gib, 1),
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1),
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'traffic': traffic[0], 'traffic_source': traffic[1],

@@ -239,15 +239,13 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
                                                       const float *__restrict__ mean,
                                                       const float *__restrict__ coef, int C,
                                                       float *__restrict__ out, int cs_out, int c_off_out,
-                                                      int C_store, int H, int W, float *__restrict__ amax)
+                                                      int C_store, int H, int W, float *__restrict__ amax, int nrows)
 {
-    // one block per grid row; a thread walks (position, channel group) pairs with stride 256 without
-    // divisions: (x, cg) += (256 / cvn, 256 % cvn) with carry.  Per-channel coefficients sit in LDS.
+    // a block takes grid rows blockIdx.x, + gridDim.x, ... (one row per block unless MMLF_BN_ROWS_PERSIST); a thread walks
+    // (position, channel group) pairs with stride 256 without divisions: (x, cg) += (256 / cvn, 256 % cvn) with carry.
+    // Per-channel coefficients sit in LDS.
     extern __shared__ float coefs[];           // [5][Cpad]: scale, shift, (mean, k1, k2, k3 for MODE 1)
     const int P = W + 2, R = H + 2;
-    const int row = blockIdx.x;
-    const int y = row % R;
-    const size_t base = (size_t)row * P;
     const int cvn = (C_store + V - 1) / V;
     const int Cpad = cvn * V;
     for (int c = threadIdx.x; c < Cpad; c += blockDim.x) {
@@ -262,8 +260,11 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
         }
     }
     __syncthreads();
-    const bool row_in = (y >= 1 && y <= H);
     const int dx = 256 / cvn, dc = 256 - dx * cvn;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int y = row % R;
+    const size_t base = (size_t)row * P;
+    const bool row_in = (y >= 1 && y <= H);
     int x = threadIdx.x / cvn, cg = threadIdx.x - x * cvn;
     float mx = 0.f;
     for (; x < P; x += dx, cg += dc) {
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
         }
     }
     if (amax) mmlf_amax_update_row(mx, amax, row);      // this workgroup wrote grid row `row`
+    }
 }
 
 // The same two passes with a FIXED channel group per thread (round 4): thread (pl, cg) owns channels 4cg .. 4cg+3 of
@@ -417,6 +419,17 @@ static inline int bn_rows_grid(int nrows, int cvn)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int g = MMLF_BN_PERSIST * cus;
+    return g < nrows ? g : nrows;
+}
+#ifndef MMLF_BN_ROWS_PERSIST
+#define MMLF_BN_ROWS_PERSIST 0  // > 0: bn_rows_kernel as that many workgroups per CU walking the grid rows (A/B)
+#endif
+static inline int bn_rows_first_grid(int nrows)
+{
+    if (MMLF_BN_ROWS_PERSIST <= 0) return nrows;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int g = MMLF_BN_ROWS_PERSIST * cus;
     return g < nrows ? g : nrows;
 }
 #ifndef MMLF_BN_ROWS_FIXED
@@ -1212,8 +1225,8 @@ extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *
         hipLaunchKernelGGL((bn_rows_fixed_kernel<0, 4>), dim3(bn_rows_grid(B * (H + 2), (C_store + 3) / 4)), dim3(threads), 0, (hipStream_t)stream, z, cs_z, nullptr, 0, 0,
                            scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out, ppi, B * (H + 2));
     else
-        hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
-                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out);
+        hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(bn_rows_first_grid(B * (H + 2))), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
+                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out, B * (H + 2));
     return mmlf_launch_status("mmlf_bn_apply_relu");
 }
 
@@ -1249,8 +1262,8 @@ extern "C" int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const fl
         hipLaunchKernelGGL((bn_rows_fixed_kernel<1, 4>), dim3(bn_rows_grid(B * (H + 2), (cs_dz + 3) / 4)), dim3(threads), 0, (hipStream_t)stream, z, cs_z, gy, cs_gy, c_off,
                            scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out, ppi, B * (H + 2));
     else
-        hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
-                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out);
+        hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(bn_rows_first_grid(B * (H + 2))), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
+                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out, B * (H + 2));
     return mmlf_launch_status("mmlf_bn_bwd_apply");
 }
 
