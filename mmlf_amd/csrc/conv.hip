@@ -990,10 +990,15 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
                 unsigned hh[4], ll[4];
                 float4 &r0 = raw[k][mb][0], &r1 = raw[k][mb][1];
                 asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
-                split2_pair_f16(r0.x, r0.y, scale_a, hh[0], ll[0]);
-                split2_pair_f16(r0.z, r0.w, scale_a, hh[1], ll[1]);
-                split2_pair_f16(r1.x, r1.y, scale_a, hh[2], ll[2]);
-                split2_pair_f16(r1.z, r1.w, scale_a, hh[3], ll[3]);
+                if constexpr (MMLF_ABL_PRESPLIT) {     // timing ablation: the operand taken as already split (wrong results on float32 input)
+                    hh[0] = __float_as_uint(r0.x); hh[1] = __float_as_uint(r0.y); hh[2] = __float_as_uint(r0.z); hh[3] = __float_as_uint(r0.w);
+                    ll[0] = __float_as_uint(r1.x); ll[1] = __float_as_uint(r1.y); ll[2] = __float_as_uint(r1.z); ll[3] = __float_as_uint(r1.w);
+                } else {
+                    split2_pair_f16(r0.x, r0.y, scale_a, hh[0], ll[0]);
+                    split2_pair_f16(r0.z, r0.w, scale_a, hh[1], ll[1]);
+                    split2_pair_f16(r1.x, r1.y, scale_a, hh[2], ll[2]);
+                    split2_pair_f16(r1.z, r1.w, scale_a, hh[3], ll[3]);
+                }
                 const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {ll[0], ll[1], ll[2], ll[3]};
                 asp[mb][0] = __builtin_bit_cast(bf16x8, vh);
                 asp[mb][1] = __builtin_bit_cast(bf16x8, vl);
@@ -1023,6 +1028,8 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
 #undef RS_TERM
             }
         }
+        // (round 4 also measured this epilogue with ROW stores -- values through a wave-private LDS image, 16-byte stores of
+        // consecutive addresses, 1 KB per wave instruction instead of 64-byte segments: 0.96-1.0 ms either way, removed)
         conv_epilogue16<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max,
                                 a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
 #pragma unroll
