@@ -896,6 +896,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
 // Layouts (mask words, statistics, amax, scales) are indexed by the global 32-position group exactly as in
 // conv4tap_x6s_kernel (tile = group / 8, wave = group % 8): the two kernels write the same bytes.
 // ---------------------------------------------------------------------------------------------
+#ifdef MMLF_RS_TIMELINE      // diagnostic build (tools/rs_timeline.py): cycles per phase of a group by the wave's own clock
+__device__ unsigned long long g_rs_timeline[5 * 4096];
+extern "C" int mmlf_debug_rs_timeline(unsigned long long *host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rs_timeline), sizeof(unsigned long long) * (size_t)n);
+}
+#define RS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
 template <int G, int NCH, int EPI>
 __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngroups)
 {
@@ -954,6 +964,9 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
     const size_t row_off = (size_t)r16 * a.cs_in;                                     // floats
     const size_t rem_off = (size_t)((q4 & 1) + (q4 >> 1) * a.P) * a.cs_in + 32 * NS;
 
+#ifdef MMLF_RS_TIMELINE
+    unsigned long long tl[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     for (; gi < gend; gi += gstep) {
         const long long Q0 = (long long)(gi >> 3) * MMLF_TILE;
         const int wv = gi & 7;
@@ -972,6 +985,7 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
                     raw[k][mb][hf] = reinterpret_cast<const float4 *>(pk + (size_t)(16 * mb) * a.cs_in)[hf];
             __builtin_amdgcn_sched_barrier(0);          // step order: the counted waits below rely on it
         }
+        RS_STAMP(0);                                     // issuing the loads
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD > 63 ? 63 : NLOAD) : "memory");
         const float scale_a = wave_operand_scale(gathered);
         const float unscale_a = 1.f / scale_a;
@@ -984,6 +998,7 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
         for (int k = 0; k < NSTEP; ++k) {
             // loads come back in order: step k's four are done once at most 4 (NSTEP - 1 - k) younger ones are outstanding
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTEP - 1 - k) > 63 ? 63 : 4 * (NSTEP - 1 - k)) : "memory");
+            if (k == 0) RS_STAMP(1);                     // scale + wait for the first step's data (and older stores)
             bf16x8 asp[2][2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1028,17 +1043,28 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
 #undef RS_TERM
             }
         }
+        RS_STAMP(2);                                     // the steps: waits for later data, split, MFMAs
         // (round 4 also measured this epilogue with ROW stores -- values through a wave-private LDS image, 16-byte stores of
         // consecutive addresses, 1 KB per wave instruction instead of 64-byte segments: 0.96-1.0 ms either way, removed)
         conv_epilogue16<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max,
                                 a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
+        RS_STAMP(3);                                     // epilogue (the issue of its stores)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int nb = 0; nb < G; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
+#ifdef MMLF_RS_TIMELINE
+        tl[4] += 1;
+#endif
     }
+#ifdef MMLF_RS_TIMELINE
+    if (lane == 0) {
+        const int slot = ((int)blockIdx.x * 8 + w) & 4095;
+        for (int i = 0; i < 5; ++i) g_rs_timeline[5 * slot + i] = tl[i];
+    }
+#endif
     if (a.out_amax) mmlf_amax_update(run_max, a.out_amax);      // at most one atomic per wave per launch
     if (a.bn_partial) {
         __syncthreads();                                        // orders the waves' sums
