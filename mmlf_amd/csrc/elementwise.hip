@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
                                                       float *__restrict__ out, int cs_out, int c_off_out,
                                                       int C_store, int H, int W, float *__restrict__ amax, int nrows)
 {
-    // a block takes grid rows blockIdx.x, + gridDim.x, ... (one row per block unless MMLF_BN_ROWS_PERSIST); a thread walks
+    // a block takes grid rows blockIdx.x, + gridDim.x, ... (launched with one block per row); a thread walks
     // (position, channel group) pairs with stride 256 without divisions: (x, cg) += (256 / cvn, 256 % cvn) with carry.
     // Per-channel coefficients sit in LDS.
     extern __shared__ float coefs[];           // [5][Cpad]: scale, shift, (mean, k1, k2, k3 for MODE 1)
@@ -303,143 +303,10 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
     }
 }
 
-// The same two passes with a FIXED channel group per thread (round 4): thread (pl, cg) owns channels 4cg .. 4cg+3 of
-// positions pl, pl + ppi, ... of its grid row, so the per-channel coefficients live in registers (the first form walks
-// (position, channel group) pairs with stride 256 and fetches 8 / 24 coefficients from LDS per access), and the loop runs
-// in batches of four positions whose loads are all issued before the first is used: four (MODE 1: eight) 16-byte loads
-// in flight per thread instead of one (two).  blockDim = ppi * cvn rounded up to whole waves.
-#ifndef MMLF_BN_LOAD_NT
-#define MMLF_BN_LOAD_NT 0     // measured (round 4): plain loads + non-temporal stores is the fastest pair
-#endif
-#ifndef MMLF_BN_STORE_NT
-#define MMLF_BN_STORE_NT 1
-#endif
-#ifndef MMLF_BN_UN
-#define MMLF_BN_UN 4
-#endif
-#ifndef MMLF_BN_PERSIST
-#define MMLF_BN_PERSIST 8       // narrow tensors (a row is one short batch per thread): that many workgroups per CU, each
-#endif                          // walking grid rows with the grid's stride; wide tensors: one workgroup per grid row
-template <int MODE, int V>
-__global__ __launch_bounds__(512) void bn_rows_fixed_kernel(const float *__restrict__ z, int cs_z,
-                                                            const float *__restrict__ gy, int cs_gy, int c_off_gy,
-                                                            const float *__restrict__ scale,
-                                                            const float *__restrict__ shift,
-                                                            const float *__restrict__ mean,
-                                                            const float *__restrict__ coef, int C,
-                                                            float *__restrict__ out, int cs_out, int c_off_out,
-                                                            int C_store, int H, int W, float *__restrict__ amax, int ppi, int nrows)
-{
-    const int P = W + 2, R = H + 2;
-    const int cvn = (C_store + V - 1) / V;
-    const int pl = threadIdx.x / cvn, cg = threadIdx.x - pl * cvn;
-    const bool active = pl < ppi;
-    float sc[V], sh[V], mu[V], k1[V], k2[V], k3[V];
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        const int c = V * cg + k;
-        const bool ok = active && c < C;        // channels >= C: zero coefficients -> output 0
-        sc[k] = ok ? scale[c] : 0.f;
-        sh[k] = ok ? shift[c] : 0.f;
-        if (MODE == 1) {
-            mu[k] = ok ? mean[c] : 0.f;
-            k1[k] = ok ? coef[c] : 0.f;
-            k2[k] = ok ? coef[C + c] : 0.f;
-            k3[k] = ok ? coef[2 * C + c] : 0.f;
-        }
-    }
-    const bool full = V * cg + V - 1 < C_store;
-    const bool has_in = V * cg < C;
-    constexpr int UN = MMLF_BN_UN;
-    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const int y = row % R;
-        const size_t base = (size_t)row * P;
-        const bool row_in = (y >= 1 && y <= H);
-        float mx = 0.f;
-        for (int x0 = pl; active && x0 < P; x0 += UN * ppi) {
-            float zz[UN][V], gg[UN][V];
-            bool inside[UN];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int x = x0 + u * ppi;
-                inside[u] = row_in && x >= 1 && x <= W && has_in;
-                if (inside[u]) {
-                    if (MMLF_BN_LOAD_NT) {
-                        VecIO<V>::load_nt(z + (base + x) * cs_z + V * cg, zz[u]);
-                        if (MODE == 1) VecIO<V>::load_nt(gy + (base + x) * cs_gy + c_off_gy + V * cg, gg[u]);
-                    } else {
-                        VecIO<V>::load(z + (base + x) * cs_z + V * cg, zz[u]);
-                        if (MODE == 1) VecIO<V>::load(gy + (base + x) * cs_gy + c_off_gy + V * cg, gg[u]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int x = x0 + u * ppi;
-                if (x >= P) break;
-                float o[V];
-#pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    o[k] = 0.f;
-                    if (inside[u]) {
-                        const float uu = fmaf(zz[u][k], sc[k], sh[k]);
-                        if (MODE == 0) {
-                            o[k] = fmaxf(uu, 0.f);
-                        } else {
-                            const float g = uu > 0.f ? gg[u][k] : 0.f;
-                            o[k] = k1[k] * g - k2[k] - k3[k] * (zz[u][k] - mu[k]);
-                        }
-                    }
-                    mx = fmaxf(mx, fabsf(o[k]));
-                }
-                float *op = out + (base + x) * cs_out + c_off_out + V * cg;
-                if (full) {
-                    if (MMLF_BN_STORE_NT) VecIO<V>::store_nt(op, o);
-                    else VecIO<V>::store(op, o);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < V; ++k)
-                        if (V * cg + k < C_store) op[k] = o[k];
-                }
-            }
-        }
-        if (amax) mmlf_amax_update_row(mx, amax, row);      // this workgroup wrote grid row `row`
-    }
-}
-// positions per iteration and threads of a bn_rows_fixed_kernel launch over cvn channel groups
-static inline void bn_rows_fixed_cfg(int cvn, int &ppi, int &threads)
-{
-    ppi = 512 / cvn;
-    if (ppi < 1) ppi = 1;
-    threads = ((ppi * cvn + 63) / 64) * 64;
-}
-static inline int bn_rows_grid(int nrows, int cvn)
-{
-    if (MMLF_BN_PERSIST <= 0 || cvn > 32) return nrows;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int g = MMLF_BN_PERSIST * cus;
-    return g < nrows ? g : nrows;
-}
-#ifndef MMLF_BN_ROWS_PERSIST
-#define MMLF_BN_ROWS_PERSIST 0  // > 0: bn_rows_kernel as that many workgroups per CU walking the grid rows (A/B)
-#endif
-static inline int bn_rows_first_grid(int nrows)
-{
-    if (MMLF_BN_ROWS_PERSIST <= 0) return nrows;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int g = MMLF_BN_ROWS_PERSIST * cus;
-    return g < nrows ? g : nrows;
-}
-#ifndef MMLF_BN_ROWS_FIXED
-// 0 (default): bn_rows_kernel.  1: bn_rows_fixed_kernel -- round 4's A/B (profiles/r04_bn_bench_*.log, r04_ab_bench_bn.log):
-// stand-alone the two forms move the same bytes per second (apply 5.1 TB/s, backward apply 5.2-5.3 TB/s at 280 channels;
-// the device's own copy of the same tensor reaches 4.5-4.9 TB/s: a 1:1 read/write stream tops out there on this part,
-// reads alone reach 6.2-6.4), but INSIDE the training step the fixed form loses 1.2 % at bs=512 and 3 % at 64 patches
-// (1093-1098 vs 1108-1111 and 1000-1003 vs 1030-1041 patches/s, same box, interleaved runs).
-#define MMLF_BN_ROWS_FIXED 0
-#endif
+// (Round 4 measured a second form of these two passes -- a fixed channel group per thread with its coefficients in
+// registers and four positions' loads in flight, every combination of non-temporal / plain accesses, persistent row grids
+// -- and persistent row grids for the form above: the same bytes per second stand-alone, 1-3 % slower inside the step;
+// DESIGN.md section 4.8, profiles/r04_bn_bench_*.log, r04_ab_bench_bn*.log; the code is in the history: commit 5c543cc.)
 
 // NCHW <-> grid
 #define PACK_XT 128   // positions per transpose tile of pack_nchw_kernel (halved until the tile fits 64 KB: wide tensors)
@@ -1219,14 +1086,8 @@ extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *
     MMLF_CHECK_ARG(cs_z % 4 == 0 && cs_y % 2 == 0 && c_off % 2 == 0 && C <= cs_z && C_store >= C &&
                        c_off + C_store <= cs_y,
                    "mmlf_bn_apply_relu: C=%d cs_z=%d cs_y=%d c_off=%d C_store=%d", C, cs_z, cs_y, c_off, C_store);
-    int ppi, threads;
-    bn_rows_fixed_cfg((C_store + 3) / 4, ppi, threads);
-    if (MMLF_BN_ROWS_FIXED && (C_store + 3) / 4 <= 512)
-        hipLaunchKernelGGL((bn_rows_fixed_kernel<0, 4>), dim3(bn_rows_grid(B * (H + 2), (C_store + 3) / 4)), dim3(threads), 0, (hipStream_t)stream, z, cs_z, nullptr, 0, 0,
-                           scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out, ppi, B * (H + 2));
-    else
-        hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(bn_rows_first_grid(B * (H + 2))), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
-                           nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out, B * (H + 2));
+    hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
+                       nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out, B * (H + 2));
     return mmlf_launch_status("mmlf_bn_apply_relu");
 }
 
@@ -1256,14 +1117,8 @@ extern "C" int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const fl
     MMLF_CHECK_ARG(gy && z && scale && shift && save_mean && coef && dz, "mmlf_bn_bwd_apply: null pointer");
     MMLF_CHECK_ARG(cs_gy % 2 == 0 && c_off % 2 == 0 && cs_z % 4 == 0 && cs_dz % 4 == 0 && C <= cs_dz,
                    "mmlf_bn_bwd_apply: layout");
-    int ppi, threads;
-    bn_rows_fixed_cfg((cs_dz + 3) / 4, ppi, threads);
-    if (MMLF_BN_ROWS_FIXED && (cs_dz + 3) / 4 <= 512)
-        hipLaunchKernelGGL((bn_rows_fixed_kernel<1, 4>), dim3(bn_rows_grid(B * (H + 2), (cs_dz + 3) / 4)), dim3(threads), 0, (hipStream_t)stream, z, cs_z, gy, cs_gy, c_off,
-                           scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out, ppi, B * (H + 2));
-    else
-        hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(bn_rows_first_grid(B * (H + 2))), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
-                           cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out, B * (H + 2));
+    hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
+                       cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out, B * (H + 2));
     return mmlf_launch_status("mmlf_bn_bwd_apply");
 }
 
