@@ -1641,13 +1641,8 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
 #ifndef MMLF_WGRAD_EARLY
 #define MMLF_WGRAD_EARLY 1     // the wide weight gradient's early barrier + next-chunk fragment prefetch (16 VGPRs)
 #endif
-#ifdef MMLF_WGRAD_VGPRS        // experiment: cap the wide weight gradient's registers so that another kernel's waves fit beside it
-#define MMLF_WGRAD_ATTR __attribute__((amdgpu_num_vgpr(MMLF_WGRAD_VGPRS)))
-#else
-#define MMLF_WGRAD_ATTR
-#endif
 template <int MB, int NBH, int PL>
-__global__ __launch_bounds__(512, 2) MMLF_WGRAD_ATTR void wgrad4tap_x6w_kernel(WgradArgs a)
+__global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
 {
     constexpr int NB = 2 * NBH;
     const WgradScales sc = wgrad_scales<PL>(a);
