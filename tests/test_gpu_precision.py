@@ -488,8 +488,27 @@ def test_values_only_invalid_positions_read_cannot_poison_a_wave():
             assert np.isfinite(zc).all()
             got, grid = nchw_from_grid(zc, cs, cout, geo, H, W, 1)
             want = np.maximum(ref, 0.0) if relu else ref
-            rel = np.abs(got - want) / (mag + np.abs(bias)[None, :, None, None])
-            assert rel.max() <= 1.5e-6 and rel.mean() <= 6e-8, (rel.max(), rel.mean())     # float32 level (exact-f32 kernel: 2e-8 mean)
+            err = np.abs(got - want)
+            # derived bound for every valid output (f16x3_bound): M = the largest value any wave of this launch is scaled by --
+            # the 4096-row IS in the scale of the waves that hold it as a valid input row, the rows beside it 2^-12 below
+            M = float(np.abs(x).max())
+            bound = f16x3_bound(mag, np.abs(w).astype(np.float64).sum(axis=(1, 2, 3))[None, :, None, None] * M, cin) \
+                + 2.0 ** -23 * (np.abs(want) + np.abs(bias)[None, :, None, None])           # the epilogue's one rounding
+            assert (err <= bound).all(), float((err / bound).max())
+            # and float32 level against the exact-f32 kernel on the same input (measured: mean 1.1e-8 vs 1.7e-8, worst element
+            # 6e-7 vs 1.3e-6 of sum |a b| + |bias|; err / derived bound 0.08 at worst)
+            keep32, engine.CONV_MODE = engine.CONV_MODE, 'f32'
+            try:
+                z32 = geo.buf(cs, dev)
+                engine.conv(geo, xg, cs, cin, engine.pack_filter(wd, 0, False), bd, cout, z32, cs, geo.P + 1, H, W, relu)
+            finally:
+                engine.CONV_MODE = keep32
+            got32, _ = nchw_from_grid(z32.cpu().numpy(), cs, cout, geo, H, W, 1)
+            rel = err / (mag + np.abs(bias)[None, :, None, None])
+            rel32 = np.abs(got32 - want) / (mag + np.abs(bias)[None, :, None, None])
+            print(f'poison relu={relu}: f16x3 mean {rel.mean():.2e} max {rel.max():.2e}; exact f32 mean {rel32.mean():.2e} max {rel32.max():.2e}; '
+                  f'max err / derived bound {float((err / bound).max()):.3f}')
+            assert rel.mean() <= 1.5 * rel32.mean()
             # nothing outside the valid extent
             border = grid.copy()
             border[:, 1:1 + H, 1:1 + W, :] = 0
