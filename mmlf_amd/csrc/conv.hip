@@ -100,6 +100,9 @@ __device__ __forceinline__ void mmlf_set_prio(int level)
 #define MMLF_ABL_PRESPLIT 0    // 1: the activation operand arrives ALREADY split -- per position and 8-channel octet 16 bytes of f16
 #endif                         // `hi` then 16 bytes of `lo`, scale 2^10 (tools/presplit_bench.py makes such a tensor): what the wide
                                // launches would take with producer-side splitting; results are correct for such input
+#ifndef MMLF_ABL_MFMA32
+#define MMLF_ABL_MFMA32 0      // 1: timing ablation of the 280-wide f16 kernel on v_mfma_f32_32x32x16_f16 -- the same fragment reads,
+#endif                         // registers and matrix-pipe cycles in half the MFMA instructions (operands not re-laid-out: WRONG results)
 #ifndef MMLF_ABL_NOEARLY
 #define MMLF_ABL_NOEARLY 0     // 1: no early barrier / next-chunk fragment prefetch (the registers a 4-row-block wave cannot spare)
 #endif
@@ -808,6 +811,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                 X6_TERM(1, 0);
                 X6_TERM(0, 1);
                 X6_TERM(0, 0);
+            } else if constexpr (MMLF_ABL_MFMA32 && G == 18) {
+                // every second column block: six 32x32x16 instructions on a 16-register accumulator made of this and the
+                // next column block's tiles, fed with the fragments at hand (row blocks as the two K halves)
+                if ((g & 1) == 0) {
+                    f32x16 t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { t[r] = acc[0][g][r]; t[4 + r] = acc[1][g][r]; t[8 + r] = acc[0][g + 1][r]; t[12 + r] = acc[1][g + 1][r]; }
+#define H32_TERM(pa, pb)                                                                                     \
+    _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),                   \
+                                                   __builtin_bit_cast(f16x8, bq[(g + mb) % 3][pb]), t, 0, 0, 0)
+                    H32_TERM(1, 0);
+                    H32_TERM(0, 1);
+                    H32_TERM(0, 0);
+#undef H32_TERM
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acc[0][g][r] = t[r]; acc[1][g][r] = t[4 + r]; acc[0][g + 1][r] = t[8 + r]; acc[1][g + 1][r] = t[12 + r]; }
+                }
             } else {
                 // MMLF_ABL_TERMS (ablation builds only, WRONG results): run 2 or 1 of the three cross terms with everything
                 // else unchanged -- the time a launch would take with fewer matrix instructions per product
