@@ -210,6 +210,41 @@ def test_conditioned_train_step_gradients_at_float32_level(variant, mode, monkey
     assert np.median(ratios) <= 1.6 and np.percentile(ratios, 90) <= 2.0, (np.median(ratios), np.percentile(ratios, 90))
 
 
+@pytest.mark.parametrize('W', [125, 126, 200])
+def test_train_and_eval_across_the_narrow_kernel_switch(W):
+    """The 27 -> 70 / 70 -> 70 layers run the tiled sixteen-wave kernel up to a pitch of 127 positions (W <= 125) and the
+    register-streamed kernel above it (full frames): the full-width net on both sides of the switch -- eval forward, and a
+    train-mode forward + backward with every parameter gradient -- against the stock torch ops of the same module."""
+    kw = dict(BASE_KW, model_uncert=True)
+    state = synth.synth_state(synth.param_spec(**kw), seed=31)
+    dev = _dev()
+    gen = torch.Generator(device=dev).manual_seed(W)
+    B, H = 2, 12
+    stacks = [torch.rand((B, 9, 3, H, W), device=dev, generator=gen) for _ in range(4)]
+    gt = 4.0 * torch.rand((B, H, W), device=dev, generator=gen) - 2.0
+    res = {}
+    for path in ('native', 'torch'):
+        m = _model(kw, state)
+        if path == 'torch':
+            m._native_ok = False
+        m.eval()
+        with torch.no_grad():
+            ev = m(*stacks)
+        m.train()
+        out = m(*stacks)
+        lossv = (torch.exp(-out['logvar']) * torch.abs(out['mean'] - gt) + out['logvar']).mean()
+        lossv.backward()
+        res[path] = (ev['mean'].cpu(), ev['logvar'].cpu(), float(lossv), {n: p.grad.cpu() for n, p in m.named_parameters()})
+    a, b = res['native'], res['torch']
+    assert float((a[0] - b[0]).abs().mean()) <= DEPTH_MAE_TOL and float((a[1] - b[1]).abs().mean()) <= DEPTH_MAE_TOL
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-4)
+    floor = 1e-4 * max(float(g.norm()) for g in b[3].values())
+    for n, ref in b[3].items():
+        if n.endswith('.2.bias') and not n.startswith('out_net.7.'):
+            continue        # conv bias in front of BatchNorm: true-zero gradient
+        assert float((a[3][n] - ref).norm()) <= 3e-2 * float(ref.norm()) + floor, n
+
+
 def test_dpp_with_eleven_views_runs_natively():
     """--model_views 11 gives the DPP head 4*11*3 = 132 channels (channel stride 136): forward, the NCHW pack of its
     gradient (a transpose tile that must not depend on the channel count) and backward against the stock torch ops"""
