@@ -41,7 +41,7 @@ const char *mmlf_last_error(void);
 /* Bumped whenever an entry point's arguments or a layout they share changes.  mmlf_abi_version() returns the value the
  * library was BUILT with: a binding compares it with the header it was written against (mmlf_amd/_lib.py does, and reads
  * the number from this line) before making any other call. */
-#define MMLF_ABI_VERSION 5
+#define MMLF_ABI_VERSION 6
 int mmlf_abi_version(void);
 
 /* number of positions a grid buffer must provide for batch B and image extent H x W */
@@ -92,12 +92,16 @@ int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void *packed, co
  *  - activations: one scale per wave (32 output positions), from the maxima of the grid rows its taps read
  *    (2-3 image rows of one patch); elements within 2^-18 of that maximum keep all 22 bits;
  *  - weights: one scale per packed column (= output channel of the launch), chosen by mmlf_pack_filter_h2.
- * "amax array" of a grid tensor (mmlf_amax_entries(B,H,W) floats): [0] = max |x| of the tensor, [1 + r] =
- * max |x| of grid row r = q / P, all channels.  Every kernel that writes a grid tensor raises the entries of
- * what it wrote by atomic max (`amax_out` arguments; upper bounds are as good as exact values);
- * mmlf_zero_slack zeroes them together with the buffer's slack, before the tensor's first producer.
+ * "amax array" of a grid tensor (mmlf_amax_entries(B,H,W) floats): a head of mmlf_amax_head() floats that holds 64
+ * partial maxima of |x| over the tensor, mmlf_amax_shard_stride() floats apart (the tensor's maximum is the largest of
+ * them; one slot would serialise a hundred thousand atomics per launch at the memory side), then [head + r] = max |x|
+ * of grid row r = q / P, all channels.  Every kernel that writes a grid tensor raises the entries of what it wrote by
+ * atomic max (`amax_out` arguments; upper bounds are as good as exact values); mmlf_zero_slack zeroes them together
+ * with the buffer's slack, before the tensor's first producer.
  * `packed` holds mmlf_packed_filter_h2_bytes(K, N) bytes (the columns' 1/scale factors sit behind the planes). */
 int64_t mmlf_amax_entries(int B, int H, int W);
+int mmlf_amax_head(void);
+int mmlf_amax_shard_stride(void);
 int64_t mmlf_packed_filter_h2_bytes(int K, int N);
 int mmlf_pack_filter_h2(const float *w_oihw, void *packed, int Cout, int Cin, int variant, int dgrad, void *stream);
 /* The same for MANY filters in one launch (a training step packs every filter of the net twice -- forward and data
@@ -194,6 +198,12 @@ int mmlf_bn_stats_finalize(const double *partial, int nblocks, int C, const floa
 int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *scale, const float *shift,
                        float *y, int cs_y, int c_off, int C_store, int B, int H, int W,
                        float *amax_out /* nullable: amax array of y */, void *stream);
+/* The same for the four stream nets' last blocks at once: y[q][k*C + c] = interior(q) ? relu(z[k][q][c]*scale[k][c] +
+ * shift[k][c]) : 0 for k = 0..3 -- ONE pass that writes whole rows of the concat buffer (cs_y == 4*C, C even) instead of
+ * four passes that each write a quarter of every row (torch.cat of the streams, feed_forward.py:266-267). */
+int mmlf_bn_apply_relu4(const float *const z[4], int cs_z, int C, const float *const scale[4],
+                        const float *const shift[4], float *y, int cs_y, int B, int H, int W,
+                        float *amax_out /* nullable: amax array of y */, void *stream);
 /* BatchNorm2d + ReLU backward, pass 1: per-channel sums of g and g*zhat with
  * g = gy * (z*scale+shift > 0); emits dgamma, dbeta (accumulating) and coefficients k[3*C]. */
 int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,

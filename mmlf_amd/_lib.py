@@ -30,6 +30,8 @@ SIGNATURES = {
     'mmlf_conv2x2_wgrad_h2': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'mmlf_packed_filter_h2_bytes': (_i64, [_i, _i]),
     'mmlf_amax_entries': (_i64, [_i, _i, _i]),
+    'mmlf_amax_head': (_i, []),
+    'mmlf_amax_shard_stride': (_i, []),
     'mmlf_pack_filter_h2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_packed_filter_h2_columns': (_i, [_i]),
     'mmlf_pack_filters_h2': (_i, [_vp, _i, _i, _vp]),
@@ -47,6 +49,7 @@ SIGNATURES = {
     'mmlf_bn_coeffs_eval': (_i, [_vp, _vp, _vp, _vp, _d, _vp, _vp, _i, _vp]),
     'mmlf_fold_bn_eval': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'mmlf_bn_apply_relu': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'mmlf_bn_apply_relu4': (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'mmlf_bn_bwd_reduce': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_bn_bwd_apply': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'mmlf_pack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),

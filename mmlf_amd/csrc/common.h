@@ -69,10 +69,19 @@ static inline Grid make_grid(int B, int H, int W)
 static inline long long grid_alloc_positions(const Grid &g) { return g.NQpad + g.P + 8 + 64; }
 
 // ---- max |x| bookkeeping of the f16-split arithmetic ("amax array" of a grid tensor) ----
-// [0] = max |x| over the whole tensor, [1 + r] = max |x| over grid row r = q / P (all channels).  Entries are
-// upper bounds raised by atomic max (non-negative floats order like their bit patterns); mmlf_zero_slack zeroes
-// them before the first producer of the tensor runs.  Rows past B*R (tile padding, tap slack) stay zero.
-static inline long long amax_entries(const Grid &g) { return 1 + (g.NQpad + 2 * g.P + 64) / g.P + 2; }
+// [k * MMLF_AMAX_SHARD_STRIDE], k < MMLF_AMAX_SHARDS: partial maxima of |x| over the whole tensor -- the tensor's maximum
+// is the largest of them (mmlf_amax_tensor_max); [MMLF_AMAX_HEAD + r] = max |x| over grid row r = q / P (all channels).
+// Entries are raised by fire-and-forget atomic max (non-negative floats order like their bit patterns);
+// mmlf_zero_slack zeroes them before the first producer of the tensor runs.  Rows past B*R (tile padding, tap slack)
+// stay zero.  Why shards: a kernel with one workgroup per grid row raises the tensor's maximum once per wave, 25 000 -
+// 200 000 times per launch; on ONE address that is 1-4 ns each at the memory side (agent-scope atomics and loads do not
+// stop at an XCD's L2): 1.1 % of a bs=512 step, 3 % of a 64-patch step (profiles/r04_ab_amax_variants.log).  64 slots,
+// 256 bytes apart, and no read-before-raise (a wave never waits for the counter) removed that.
+#define MMLF_AMAX_SHARDS 64
+#define MMLF_AMAX_SHARD_STRIDE 64
+#define MMLF_AMAX_HEAD (MMLF_AMAX_SHARDS * MMLF_AMAX_SHARD_STRIDE)
+static inline long long amax_rows(const Grid &g) { return (g.NQpad + 2 * g.P + 64) / g.P + 2; }
+static inline long long amax_entries(const Grid &g) { return MMLF_AMAX_HEAD + amax_rows(g); }
 
 // n / d == (n * m) >> sh for 0 <= n < 2^31 (Granlund-Montgomery round-up magic, N = 31)
 struct Magic { unsigned m; int sh; };
@@ -110,37 +119,36 @@ __host__ __device__ static inline int master_tap(int t, int variant)
     return dx * 2 + (1 - dy);                     // transpose, then flip along kernel-H
 }
 
-// Running max |x| of a tensor in a device scalar (non-negative floats order like their bit patterns).
-// Every thread of the block calls it with its own maximum; the atomic is skipped when the scalar already
-// holds a larger value (a stale read only costs an extra atomic), so a launch issues few of them.
-// fire-and-forget form for hot epilogues: no read of the slot, nothing to wait for
+// Running maxima in device memory: fire-and-forget atomic max -- no read of the slot, nothing to wait for.
 __device__ __forceinline__ void mmlf_amax_raise_nowait(float *slot_f, float m)
 {
     (void)__hip_atomic_fetch_max(reinterpret_cast<unsigned *>(slot_f), __float_as_uint(m), __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void mmlf_amax_raise(float *slot_f, float m)
-{
-    const unsigned bits = __float_as_uint(m);
-    unsigned *slot = reinterpret_cast<unsigned *>(slot_f);
-    if (bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
 }
 __device__ __forceinline__ float mmlf_wave_max(float m)
 {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     return m;
 }
-__device__ __forceinline__ void mmlf_amax_update(float m, float *amax)
+// every lane of the wave calls it with its own maximum; `shard` (any integer, wave-uniform) picks the slot
+__device__ __forceinline__ void mmlf_amax_update(float m, float *amax, unsigned shard)
 {
     m = mmlf_wave_max(m);
-    if ((threadIdx.x & 63) == 0) mmlf_amax_raise(amax, m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f)
+        mmlf_amax_raise_nowait(amax + (shard % MMLF_AMAX_SHARDS) * MMLF_AMAX_SHARD_STRIDE, m);
 }
-// the same for a kernel whose workgroup writes ONE grid row: raises the tensor's and the row's entry
+// the same for a kernel whose workgroup writes (part of) ONE grid row: raises a tensor shard and the row's entry
 __device__ __forceinline__ void mmlf_amax_update_row(float m, float *amax, int row)
 {
     m = mmlf_wave_max(m);
     if ((threadIdx.x & 63) == 0 && m > 0.f) {
-        mmlf_amax_raise(amax, m);
-        mmlf_amax_raise(amax + 1 + row, m);
+        mmlf_amax_raise_nowait(amax + ((unsigned)row % MMLF_AMAX_SHARDS) * MMLF_AMAX_SHARD_STRIDE, m);
+        mmlf_amax_raise_nowait(amax + MMLF_AMAX_HEAD + row, m);
     }
+}
+// max |x| of the tensor from its shards; all 64 lanes of the wave must call it (the result is wave-uniform)
+__device__ __forceinline__ float mmlf_amax_tensor_max(const float *amax)
+{
+    static_assert(MMLF_AMAX_SHARDS == 64, "one shard per lane");
+    return mmlf_wave_max(amax[(threadIdx.x & 63) * MMLF_AMAX_SHARD_STRIDE]);
 }

@@ -460,10 +460,10 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
         m_lo = mmlf_wave_max(m_lo);
         m_hi = mmlf_wave_max(m_hi);
         if (r16 + 16 * q4 == 0) {
-            if (m_lo > 0.f) mmlf_amax_raise_nowait(a.out_amax + 1 + rd0, m_lo);
+            if (m_lo > 0.f) mmlf_amax_raise_nowait(a.out_amax + MMLF_AMAX_HEAD + rd0, m_lo);
             if (m_hi > 0.f) {
                 const unsigned rdl = fastdiv(d0 + 31, a.divP);
-                for (unsigned r = rd0 + 1; r <= rdl; ++r) mmlf_amax_raise_nowait(a.out_amax + 1 + r, m_hi);
+                for (unsigned r = rd0 + 1; r <= rdl; ++r) mmlf_amax_raise_nowait(a.out_amax + MMLF_AMAX_HEAD + r, m_hi);
             }
             run_max = fmaxf(run_max, fmaxf(m_lo, m_hi));        // lane 0 carries the tensor maximum
         }
@@ -485,7 +485,7 @@ __device__ __forceinline__ float wave_operand_amax_gather(const ConvArgs &a, lon
         const unsigned r0 = fastdiv((unsigned)q0, a.divP);
         unsigned r1 = fastdiv((unsigned)ql, a.divP);
         r1 += (r1 - fastdiv(r1, a.divR) * (unsigned)a.R != (unsigned)(a.R - 1)) ? 1u : 0u;
-        for (unsigned r = r0 + lane; r <= r1; r += 64) m = fmaxf(m, a.in_amax[1 + r]);
+        for (unsigned r = r0 + lane; r <= r1; r += 64) m = fmaxf(m, a.in_amax[MMLF_AMAX_HEAD + r]);
     }
     return m;
 }
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     }
     if constexpr (EARLY) __syncthreads();                       // orders the last tile's wave sums
     const ConvArgs e = late_args();
-    if (e.out_amax) mmlf_amax_update(run_max, e.out_amax);      // at most one atomic per wave per launch
+    if (e.out_amax) mmlf_amax_update(run_max, e.out_amax, blockIdx.x * NW + w);      // one atomic per wave per launch
     if (e.bn_partial) {                                         // the loop's last barrier ordered the wave sums
         for (int k = tid; k < 2 * e.n_true; k += 64 * NW) {
             const int ch = k % e.n_true, which = k / e.n_true;
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
         for (int i = 0; i < 5; ++i) g_rs_timeline[5 * slot + i] = tl[i];
     }
 #endif
-    if (a.out_amax) mmlf_amax_update(run_max, a.out_amax);      // at most one atomic per wave per launch
+    if (a.out_amax) mmlf_amax_update(run_max, a.out_amax, blockIdx.x * 8 + w);      // one atomic per wave per launch
     if (a.bn_partial) {
         __syncthreads();                                        // orders the waves' sums
         for (int k = tid; k < 2 * a.n_true; k += 512) {
@@ -1247,6 +1247,32 @@ struct WgradArgs {
     const float *chunk_scales;       // f16 split: [nchunks][2] power-of-two operand scales (wgrad_chunk_scales_kernel)
 };
 
+// Block -> (slice, position split).  Blocks b, b + 8, ... land on one XCD (round-robin dispatch): the slices of one split are
+// placed there and share its L2 for their gradient reads.  nsplit need not be a multiple of 8: the 8 * (nsplit / 8) regular
+// splits are numbered as they always were (same partial-sum order), the slices of the remaining ones are dealt behind them,
+// `per` blocks to an XCD, consecutive slices together (their gradient reads come from memory once per XCD they touch: a few
+// percent of the launch's reads at 2 of 42 splits).
+__device__ __forceinline__ bool wgrad_block_map(const WgradArgs &a, int &slice, int &split)
+{
+    const int b = blockIdx.x, x = b & 7, j = b >> 3;
+    const int reg = (a.nsplit >> 3) * a.nslice;           // regular blocks per XCD
+    if (j < reg) {
+        slice = j % a.nslice;
+        split = (j / a.nslice) * 8 + x;
+        return true;
+    }
+    const int left = (a.nsplit & 7) * a.nslice, per = (left + 7) >> 3;
+    const int m = x * per + (j - reg);
+    slice = m % a.nslice;
+    split = (a.nsplit & ~7) + m / a.nslice;
+    return m < left;
+}
+
+static inline unsigned wgrad_grid_blocks(int nslice, int nsplit)
+{
+    return 8u * (unsigned)((nsplit >> 3) * nslice + ((nsplit & 7) * nslice + 7) / 8);
+}
+
 #define WG_KQ 32  // positions per chunk
 
 // 256 threads = 4 waves, wave t = tap t.  Block = (32-channel ci slice, position split).
@@ -1267,11 +1293,8 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_kernel(WgradArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63, t = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
-    const int b = blockIdx.x;
-    const int kk = b >> 3;
-    const int slice = kk % a.nslice;
-    const int split = (kk / a.nslice) * 8 + (b & 7);
-    if (split >= a.nsplit) return;
+    int slice, split;
+    if (!wgrad_block_map(a, slice, split)) return;
     const int ci0 = slice * 32;
     int c_begin = split * a.chunks_per_split;
     int c_end = c_begin + a.chunks_per_split;
@@ -1430,8 +1453,9 @@ template <int PL> __device__ __forceinline__ WgradScales wgrad_scales(const Wgra
 {
     WgradScales s = {1.f, 1.f};
     if constexpr (PL == 2) {
-        s.inv_sa = 1.f / pow2_scale_for(a.in_amax[0]);
-        s.inv_sg = 1.f / pow2_scale_for(a.g_amax[0]);
+        // left behind the per-chunk scales by wgrad_chunk_scales_kernel (the tensors' maxima live in 64 shards)
+        s.inv_sa = a.chunk_scales[2 * (size_t)a.nchunks];
+        s.inv_sg = a.chunk_scales[2 * (size_t)a.nchunks + 1];
     }
     return s;
 }
@@ -1448,7 +1472,7 @@ template <int PL> __device__ __forceinline__ void wgrad_chunk_scale(const WgradA
 }
 struct ChunkScaleArgs {
     const float *in_amax, *g_amax;
-    float *out;                      // [nchunks][2]
+    float *out;                      // [nchunks][2], then 1 / sA, 1 / sG of the two tensors
     long long NQ;
     int nchunks, P, g_shift, nrows;
     Magic divP;
@@ -1457,8 +1481,12 @@ __device__ __forceinline__ int pow2_exponent(float p) { return (int)(__float_as_
 __global__ __launch_bounds__(256) void wgrad_chunk_scales_kernel(ChunkScaleArgs a)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
+    const float sA = pow2_scale_for(mmlf_amax_tensor_max(a.in_amax)), sG = pow2_scale_for(mmlf_amax_tensor_max(a.g_amax));
+    if (c == 0) {                                   // the tensors' scales (inverted) for the weight-gradient kernel
+        a.out[2 * (size_t)a.nchunks] = 1.f / sA;
+        a.out[2 * (size_t)a.nchunks + 1] = 1.f / sG;
+    }
     if (c >= a.nchunks) return;
-    const float sA = pow2_scale_for(a.in_amax[0]), sG = pow2_scale_for(a.g_amax[0]);
     const long long q0 = (long long)c * WG_KQ;
     int x = 0;
     if (q0 < a.NQ) {
@@ -1470,11 +1498,11 @@ __global__ __launch_bounds__(256) void wgrad_chunk_scales_kernel(ChunkScaleArgs 
         unsigned r1 = fastdiv((unsigned)(ql + a.P + 1), a.divP);
         if (r1 >= (unsigned)a.nrows) r1 = a.nrows - 1;
         float ma = 0.f, mg = 0.f;
-        for (unsigned r = r0; r <= r1; ++r) ma = fmaxf(ma, a.in_amax[1 + r]);
+        for (unsigned r = r0; r <= r1; ++r) ma = fmaxf(ma, a.in_amax[MMLF_AMAX_HEAD + r]);
         const unsigned g0 = fastdiv((unsigned)(q0 + a.g_shift), a.divP);
         unsigned g1 = fastdiv((unsigned)(ql + a.g_shift), a.divP);
         if (g1 >= (unsigned)a.nrows) g1 = a.nrows - 1;
-        for (unsigned r = g0; r <= g1; ++r) mg = fmaxf(mg, a.g_amax[1 + r]);
+        for (unsigned r = g0; r <= g1; ++r) mg = fmaxf(mg, a.g_amax[MMLF_AMAX_HEAD + r]);
         // headroom (binades) of the chunk's operands under the global scales; an all-zero operand takes any scale
         const int u = ma > 0.f ? pow2_exponent(pow2_scale_for(ma)) - pow2_exponent(sA) : 60;
         const int v = mg > 0.f ? pow2_exponent(pow2_scale_for(mg)) - pow2_exponent(sG) : 60;
@@ -1517,12 +1545,8 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63, t = tid >> 6;
     const int r16 = lane & 15, q4 = lane >> 4;
-    // blocks b and b+8 share an XCD: the slices of one position split sit on one L2 and share its g reads
-    const int b = blockIdx.x;
-    const int kk = b >> 3;
-    const int slice = kk % a.nslice;
-    const int split = (kk / a.nslice) * 8 + (b & 7);
-    if (split >= a.nsplit) return;
+    int slice, split;
+    if (!wgrad_block_map(a, slice, split)) return;
     const int ci0 = slice * 16 * MB;
     int c_begin = split * a.chunks_per_split;
     int c_end = c_begin + a.chunks_per_split;
@@ -1682,11 +1706,8 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = w & 3, h = w >> 2;
     const int r16 = lane & 15, q4 = lane >> 4;
-    const int b = blockIdx.x;
-    const int kk = b >> 3;
-    const int slice = kk % a.nslice;
-    const int split = (kk / a.nslice) * 8 + (b & 7);
-    if (split >= a.nsplit) return;
+    int slice, split;
+    if (!wgrad_block_map(a, slice, split)) return;
     const int ci0 = slice * 16 * MB;
     const int c_begin = split * a.chunks_per_split;
     int c_end = c_begin + a.chunks_per_split;
@@ -1968,7 +1989,9 @@ static inline bool wgrad16_cfg(int Cin, int Cout, Wgrad16Cfg *c)
     if (c->nb == 18) {           // wgrad4tap_x6w_kernel: one 512-thread workgroup per CU, three even rounds
         c->mb = 3;
         c->nslice = (Cin + 1 + 47) / 48;
-        c->nsplit = (768 / c->nslice + 7) / 8 * 8;
+        c->nsplit = 256 / c->nslice;     // ONE round on 256 CUs (252 workgroups at six slices)
+        static const int forced = [] { const char *e = getenv("MMLF_WGRAD_NSPLIT"); return e ? atoi(e) : 0; }();
+        if (forced > 0) c->nsplit = forced;                      // A/B switch (tools/ab_env.sh)
         if (c->nsplit < 8) c->nsplit = 8;
     } else {                     // wgrad4tap_x6n_kernel: two 256-thread workgroups per CU
         c->mb = (c->nb <= 5 && Cin + 1 > 32 && Cin + 1 <= 80) ? 5 : 2;
@@ -1997,7 +2020,7 @@ extern "C" int64_t mmlf_wgrad_workspace_floats(int Cin, int Cout, int B, int H, 
 {
     const int64_t n = wgrad_partial_floats(Cin, Cout);
     if (n < 0 || B <= 0 || H <= 0 || W <= 0) return -1;
-    return n + 2 * (make_grid(B, H, W).NQpad / WG_KQ);      // + the f16 split's per-chunk operand scales
+    return n + 2 * (make_grid(B, H, W).NQpad / WG_KQ) + 4;  // + the f16 split's per-chunk operand scales and the two tensor scales
 }
 
 extern "C" int mmlf_pack_filter(const float *w, float *packed, int Cout, int Cin, int variant, int dgrad,
@@ -2066,7 +2089,7 @@ template <int NT>
 static int launch_wgrad(const WgradArgs &a, hipStream_t st)
 {
     constexpr size_t lds = (2 * 33 * 32 + WG_KQ * NT * 32) * sizeof(float);
-    hipLaunchKernelGGL(wgrad4tap_kernel<NT>, dim3((unsigned)(a.nslice * a.nsplit)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(wgrad4tap_kernel<NT>, dim3(wgrad_grid_blocks(a.nslice, a.nsplit)), dim3(256), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad");
 }
 
@@ -2079,7 +2102,7 @@ static int launch_wgrad16(const WgradArgs &a, hipStream_t st)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6n_kernel<MB, NB, PL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL((wgrad4tap_x6n_kernel<MB, NB, PL>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((wgrad4tap_x6n_kernel<MB, NB, PL>), dim3(wgrad_grid_blocks(a.nslice, a.nsplit)), dim3(256), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
 }
 
@@ -2092,7 +2115,7 @@ static int launch_wgrad_wide(const WgradArgs &a, hipStream_t st)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6w_kernel<3, 9, PL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    hipLaunchKernelGGL((wgrad4tap_x6w_kernel<3, 9, PL>), dim3((unsigned)(a.nslice * a.nsplit)), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((wgrad4tap_x6w_kernel<3, 9, PL>), dim3(wgrad_grid_blocks(a.nslice, a.nsplit)), dim3(512), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
 }
 
@@ -2168,7 +2191,7 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
         ChunkScaleArgs ca;
         ca.in_amax = in_amax; ca.g_amax = g_amax; ca.out = workspace + wgrad_partial_floats(Cin, Cout);
         ca.NQ = gr.NQ; ca.nchunks = a.nchunks; ca.P = gr.P; ca.g_shift = g_shift;
-        ca.nrows = (int)amax_entries(gr) - 1;
+        ca.nrows = (int)amax_rows(gr);
         ca.divP = make_magic((unsigned)gr.P);
         hipLaunchKernelGGL(wgrad_chunk_scales_kernel, dim3((a.nchunks + 255) / 256), dim3(256), 0, st, ca);
         a.chunk_scales = ca.out;

@@ -13,6 +13,8 @@ extern "C" int64_t mmlf_amax_entries(int B, int H, int W)
     if (B <= 0 || H <= 0 || W <= 0) return -1;
     return amax_entries(make_grid(B, H, W));
 }
+extern "C" int mmlf_amax_head(void) { return MMLF_AMAX_HEAD; }
+extern "C" int mmlf_amax_shard_stride(void) { return MMLF_AMAX_SHARD_STRIDE; }
 extern "C" int64_t mmlf_grid_alloc_positions(int B, int H, int W)
 {
     if (B <= 0 || H <= 0 || W <= 0) return -1;
@@ -243,7 +245,8 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
 {
     // a block takes grid rows blockIdx.x, + gridDim.x, ... (launched with one block per row); a thread walks
     // (position, channel group) pairs with stride 256 without divisions: (x, cg) += (256 / cvn, 256 % cvn) with carry.
-    // Per-channel coefficients sit in LDS.
+    // Per-channel coefficients sit in LDS.  (Quarter rows per block -- 8 % faster stand-alone at 64 patches, where whole
+    // rows leave a tail of blocks on an empty chip -- cost 4 ms per 60 ms step inside it: profiles/r04_ab64_bn_row_segments.log.)
     extern __shared__ float coefs[];           // [5][Cpad]: scale, shift, (mean, k1, k2, k3 for MODE 1)
     const int P = W + 2, R = H + 2;
     const int cvn = (C_store + V - 1) / V;
@@ -300,6 +303,49 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
         }
     }
     if (amax) mmlf_amax_update_row(mx, amax, row);      // this workgroup wrote grid row `row`
+    }
+}
+
+// BatchNorm apply + ReLU of the four stream nets' last blocks in ONE pass over the concat buffer (torch.cat,
+// reference feed_forward.py:266-267): four launches that each write a 280-byte slice of every 1120-byte position row
+// run at half the rate of a dense pass (partial lines: 2.5 TB/s against 5.1); this one writes whole rows.
+// Channel PAIRS across the threads (a 70-channel slice starts on an 8-byte boundary only).
+struct BnApply4 { const float *z[4]; const float *scale[4]; const float *shift[4]; };
+__global__ __launch_bounds__(256) void bn_apply4_kernel(BnApply4 s, int cs_z, int C, float *__restrict__ out,
+                                                        int H, int W, float *__restrict__ amax, int nrows)
+{
+    extern __shared__ float coefs[];           // [2][4 * C]: scale, shift in concat order
+    const int P = W + 2, R = H + 2;
+    const int C4 = 4 * C, half = C / 2, cvn = 2 * C;     // channel pairs per position row
+    for (int c = threadIdx.x; c < C4; c += blockDim.x) {
+        const int k = c / C, cl = c - k * C;
+        const float *sc = k == 0 ? s.scale[0] : k == 1 ? s.scale[1] : k == 2 ? s.scale[2] : s.scale[3];
+        const float *sh = k == 0 ? s.shift[0] : k == 1 ? s.shift[1] : k == 2 ? s.shift[2] : s.shift[3];
+        coefs[c] = sc[cl];
+        coefs[C4 + c] = sh[cl];
+    }
+    __syncthreads();
+    const int dx = 256 / cvn, dc = 256 - dx * cvn;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int y = row % R;
+        const size_t base = (size_t)row * P;
+        const bool row_in = (y >= 1 && y <= H);
+        int x = threadIdx.x / cvn, g = threadIdx.x - x * cvn;
+        float mx = 0.f;
+        for (; x < P; x += dx, g += dc) {
+            if (g >= cvn) { g -= cvn; ++x; if (x >= P) break; }
+            float2 o = make_float2(0.f, 0.f);
+            if (row_in && x >= 1 && x <= W) {
+                const int k = g / half, cl = 2 * (g - k * half);
+                const float *zp = k == 0 ? s.z[0] : k == 1 ? s.z[1] : k == 2 ? s.z[2] : s.z[3];
+                const float2 zz = *reinterpret_cast<const float2 *>(zp + (base + x) * cs_z + cl);
+                o.x = fmaxf(fmaf(zz.x, coefs[2 * g], coefs[C4 + 2 * g]), 0.f);
+                o.y = fmaxf(fmaf(zz.y, coefs[2 * g + 1], coefs[C4 + 2 * g + 1]), 0.f);
+            }
+            mx = fmaxf(mx, fmaxf(o.x, o.y));
+            *reinterpret_cast<float2 *>(out + (base + x) * C4 + 2 * g) = o;
+        }
+        if (amax) mmlf_amax_update_row(mx, amax, row);
     }
 }
 
@@ -476,9 +522,13 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(int kind, const float
 
 __global__ void loss_finalize_kernel(double *scratch, int nblocks, float *loss_out, const double *den_override)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wave, fixed order: lane l sums blocks l, l + 64, ..., then a butterfly (a single thread walking 1024 dependent
+    // loads took 88 us)
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     double cnt = 0, sum = 0;
-    for (int b = 0; b < nblocks; ++b) { cnt += scratch[2 + 2 * b]; sum += scratch[3 + 2 * b]; }
+    for (int b = threadIdx.x; b < nblocks; b += 64) { cnt += scratch[2 + 2 * b]; sum += scratch[3 + 2 * b]; }
+    for (int off = 32; off; off >>= 1) { cnt += __shfl_xor(cnt, off); sum += __shfl_xor(sum, off); }
+    if (threadIdx.x != 0) return;
     if (den_override) cnt = *den_override;
     const double den = cnt == 0 ? 1.0 : cnt;
     scratch[0] = 1.0 / den;
@@ -578,13 +628,17 @@ __global__ __launch_bounds__(256) void loss_multi_aux_kernel(MultiLossArgs a)
 }
 __global__ void loss_multi_aux_finalize_kernel(MultiLossArgs a)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;        // one wave, fixed order (as loss_finalize_kernel)
     double s0 = 0, s1 = 0;
     if (a.aux_override) { s0 = a.aux_override[0]; s1 = a.aux_override[1]; }
-    else for (int b = 0; b < a.nblocks; ++b) {
-        s0 += a.scratch[2 + 2 * a.nblocks + 2 + 2 * b];
-        s1 += a.scratch[2 + 2 * a.nblocks + 3 + 2 * b];
+    else {
+        for (int b = threadIdx.x; b < a.nblocks; b += 64) {
+            s0 += a.scratch[2 + 2 * a.nblocks + 2 + 2 * b];
+            s1 += a.scratch[2 + 2 * a.nblocks + 3 + 2 * b];
+        }
+        for (int off = 32; off; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
     }
+    if (threadIdx.x != 0) return;
     a.scratch[2 + 2 * a.nblocks] = s0;
     a.scratch[2 + 2 * a.nblocks + 1] = s1;
 }
@@ -1086,9 +1140,28 @@ extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *
     MMLF_CHECK_ARG(cs_z % 4 == 0 && cs_y % 2 == 0 && c_off % 2 == 0 && C <= cs_z && C_store >= C &&
                        c_off + C_store <= cs_y,
                    "mmlf_bn_apply_relu: C=%d cs_z=%d cs_y=%d c_off=%d C_store=%d", C, cs_z, cs_y, c_off, C_store);
-    hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(B * (H + 2)), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
-                       nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out, B * (H + 2));
+    const int nrows = B * (H + 2);
+    hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(nrows), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
+                       nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out, nrows);
     return mmlf_launch_status("mmlf_bn_apply_relu");
+}
+
+extern "C" int mmlf_bn_apply_relu4(const float *const z[4], int cs_z, int C, const float *const scale[4],
+                                   const float *const shift[4], float *y, int cs_y, int B, int H, int W,
+                                   float *amax_out, void *stream)
+{
+    MMLF_CHECK_ARG(z && scale && shift && y && B > 0 && H > 0 && W > 0, "mmlf_bn_apply_relu4: bad argument");
+    MMLF_CHECK_ARG(C > 0 && C % 2 == 0 && C <= cs_z && cs_z % 2 == 0 && cs_y == 4 * C && 8 * C * sizeof(float) <= 48 * 1024,
+                   "mmlf_bn_apply_relu4: C=%d cs_z=%d cs_y=%d (needs even C, cs_y == 4 * C)", C, cs_z, cs_y);
+    BnApply4 s;
+    for (int k = 0; k < 4; ++k) {
+        MMLF_CHECK_ARG(z[k] && scale[k] && shift[k], "mmlf_bn_apply_relu4: null pointer in source %d", k);
+        s.z[k] = z[k]; s.scale[k] = scale[k]; s.shift[k] = shift[k];
+    }
+    const int nrows = B * (H + 2);
+    hipLaunchKernelGGL(bn_apply4_kernel, dim3(nrows), dim3(256), 8 * C * sizeof(float), (hipStream_t)stream, s, cs_z, C,
+                       y, H, W, amax_out, nrows);
+    return mmlf_launch_status("mmlf_bn_apply_relu4");
 }
 
 extern "C" int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const float *z, int cs_z, int C,
@@ -1117,8 +1190,9 @@ extern "C" int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const fl
     MMLF_CHECK_ARG(gy && z && scale && shift && save_mean && coef && dz, "mmlf_bn_bwd_apply: null pointer");
     MMLF_CHECK_ARG(cs_gy % 2 == 0 && c_off % 2 == 0 && cs_z % 4 == 0 && cs_dz % 4 == 0 && C <= cs_dz,
                    "mmlf_bn_bwd_apply: layout");
-    hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(B * (H + 2)), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
-                       cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out, B * (H + 2));
+    const int nrows = B * (H + 2);
+    hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(nrows), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
+                       cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out, nrows);
     return mmlf_launch_status("mmlf_bn_bwd_apply");
 }
 

@@ -31,13 +31,16 @@ class Geometry:
         self.NQ = B * self.G
         self.alloc = int(_lib.load().mmlf_grid_alloc_positions(B, H, W))
         self.amax_n = int(_lib.load().mmlf_amax_entries(B, H, W))
+        self.amax_head = int(_lib.load().mmlf_amax_head())             # tensor-maximum shards, then one entry per grid row
+        self.amax_stride = int(_lib.load().mmlf_amax_shard_stride())
         if self.alloc * 288 * 4 >= 2 ** 63 or self.NQ + 2 * self.P + 600 >= 2 ** 31:
             raise ValueError('batch x image too large for 32-bit grid positions')
 
     def buf(self, cs, device):
         """Grid buffer with zeroed head/tail slack (the kernels write everything else) and its zeroed amax
-        array: [0] = max |x| of the tensor, [1 + r] = max |x| of grid row r; the tensor's producers raise the
-        entries by atomic max and the f16-split kernels derive their power-of-two operand scales from them."""
+        array: a head of 64 partial maxima of |x| over the tensor (`amax_stride` floats apart), then
+        [amax_head + r] = max |x| of grid row r; the tensor's producers raise the entries by atomic max and the
+        f16-split kernels derive their power-of-two operand scales from them (include/mmlf_hip.h)."""
         t = torch.empty(self.alloc * cs, dtype=torch.float32, device=device)
         t.absmax = torch.empty(self.amax_n, dtype=torch.float32, device=device)
         call('mmlf_zero_slack', ptr(t), cs, self.B, self.H, self.W, ptr(t.absmax), _lib.stream_ptr())
@@ -70,8 +73,16 @@ class Geometry:
         """amax array of a grid tensor that did not come from buf() (tests, tools): computed with torch ops."""
         rows = t[:self.NQ * cs].view(self.B * self.R, self.P * cs).abs().amax(1)
         out = torch.zeros(self.amax_n, dtype=torch.float32, device=t.device)
-        out[0] = rows.max()
-        out[1:1 + rows.numel()] = rows
+        out[0] = rows.max()                # one shard holds it all
+        out[self.amax_head:self.amax_head + rows.numel()] = rows
+        return out
+
+    def amax_canonical(self, a):
+        """an amax array with the tensor maximum collapsed into shard 0 (what amax_of builds): kernels spread it over
+        the shards by wave / row, so two arrays that describe the same tensor compare equal in this form only"""
+        out = a.clone()
+        out[:self.amax_head] = 0
+        out[0] = a[:self.amax_head].max()
         return out
 
 
@@ -220,18 +231,21 @@ def _amax_of(geo, t, cs):
         return geo.amax_of(t, cs)
     if CHECK_ABSMAX:       # test hook: the producers' running maxima must be the tensor's true maxima
         true = geo.amax_of(t, cs)
+        c = geo.amax_canonical(a)
         exact = geo.P >= 32                 # smaller pitches: rows behind a wave's first get an upper bound
-        bad = (a != true) if exact else (a < true)
-        bad[0] = a[0] != true[0]
+        bad = (c != true) if exact else (c < true)
+        bad[0] = c[0] != true[0]
         if bool(bad.any()):
             k = int(bad.nonzero()[0])
-            raise AssertionError(f'amax entry {k} holds {float(a[k])!r}, true max |x| is {float(true[k])!r}')
+            raise AssertionError(f'amax entry {k} holds {float(c[k])!r}, true max |x| is {float(true[k])!r}')
     return a
 
 
 CHECK_ABSMAX = bool(os.environ.get('MMLF_CHECK_ABSMAX'))
 # one launch packs every filter of a step / zeroes the slack of a block's buffers (0: per filter, per buffer)
 BATCHED = os.environ.get('MMLF_BATCHED', '1') != '0'
+# one BatchNorm-apply pass for the four streams' last blocks (whole rows of the concat buffer); 0: four slice passes
+APPLY4 = os.environ.get('MMLF_APPLY4', '1') != '0'
 # MMLF_OVERLAP_WGRAD=1: run conv1's weight gradient of the wide blocks on a side stream beside the next BatchNorm-backward
 # kernels.  Off by default since round 3: with today's kernels the step takes the same time either way (1103-1105 patches/s
 # both, A/B on one box) -- a weight-gradient workgroup fills its CU's registers, so the two kernels time-slice the CUs
@@ -355,8 +369,11 @@ class Trunk:
         return _Workspace.get(dev).packed_filters(items)
 
     # ------------------------------------------------------------------ forward
-    def _block_fwd(self, geo, spec, var, x, cs_x, p, train, rec_list, out=None, cs_out=None, c_off=0, packs=None):
-        """x: grid tensor (extent H,W at (1,1)).  Returns the block output grid tensor."""
+    def _block_fwd(self, geo, spec, var, x, cs_x, p, train, rec_list, out=None, cs_out=None, c_off=0, packs=None,
+                   tracked=None, deferred=None):
+        """x: grid tensor (extent H,W at (1,1)).  Returns the block output grid tensor.
+        deferred (a list): the BatchNorm-apply + ReLU pass into `out` is NOT launched; (z, scale, shift) is appended
+        and the caller applies all four streams' last blocks in one pass over the concat buffer (Trunk.forward)."""
         dev = x.device
         ws = _Workspace.get(dev)
         B, H, W, P = geo.B, geo.H, geo.W, geo.P
@@ -418,7 +435,10 @@ class Trunk:
                 call('mmlf_bn_stats_train', ptr(z), cs_mid, C, ptr(g), ptr(bt), ptr(rm), ptr(rv), self.momentum,
                      self.eps, ptr(smean), ptr(sinv), ptr(scale), ptr(shift), ptr(ws.partial), BN_BLOCKS, B, H, W,
                      _lib.stream_ptr())
-            p[f'{spec.prefix}.3.num_batches_tracked'].add_(1)
+            if tracked is None:
+                p[f'{spec.prefix}.3.num_batches_tracked'].add_(1)
+            else:
+                tracked.append(p[f'{spec.prefix}.3.num_batches_tracked'])
         else:
             call('mmlf_bn_coeffs_eval', ptr(g), ptr(bt), ptr(rm), ptr(rv), self.eps, ptr(scale), ptr(shift), C,
                  _lib.stream_ptr())
@@ -429,8 +449,11 @@ class Trunk:
                 sinv.copy_(torch.rsqrt(rv.double() + self.eps).float())
                 rec['eval'] = True
         c_store = cs_out if new_out else C
-        call('mmlf_bn_apply_relu', ptr(z), cs_mid, C, ptr(scale), ptr(shift), ptr(out), cs_out, c_off, c_store,
-             B, H, W, ptr(out.absmax), _lib.stream_ptr())
+        if deferred is not None:
+            deferred.append((z, scale, shift))
+        else:
+            call('mmlf_bn_apply_relu', ptr(z), cs_mid, C, ptr(scale), ptr(shift), ptr(out), cs_out, c_off, c_store,
+                 B, H, W, ptr(out.absmax), _lib.stream_ptr())
         rec.update(scale=scale, shift=shift, smean=smean, sinv=sinv)
         if rec_list is not None:
             rec_list.append(rec)
@@ -445,9 +468,14 @@ class Trunk:
         geo = Geometry(B, H, W)
         cin0 = n * c
         packs = self._prepack(p, dev, save)
+        tracked = []                  # BatchNorm counters of this pass: ONE increment launch at its end
         tape = {'geo': geo, 'streams': [], 'out': [], 'packs': packs}
         concat, *xs = geo.bufs([4 * self.chs] + [cs_of(cin0)] * 3, dev)
         xs.append(geo.buf(cs_of(cin0), dev))
+        # the four streams' last BatchNorm-apply passes write quarter rows of the concat buffer: one pass for all four
+        # (whole rows) when they are real passes (not folded into conv2) and the channel count allows it
+        fold = not train and not save
+        deferred = [] if (APPLY4 and not fold and self.chs % 2 == 0 and all(b[-1].bn for _, _, b in self.streams)) else None
         for s, (key, var, blocks) in enumerate(self.streams):
             x = xs[s]
             call('mmlf_pack_nchw', ptr(stacks[s]), cin0, ptr(x), cs_of(cin0), B, H, W, ptr(x.absmax), _lib.stream_ptr())
@@ -456,15 +484,31 @@ class Trunk:
             for k, spec in enumerate(blocks):
                 last = k == len(blocks) - 1
                 x, cs_x = self._block_fwd(geo, spec, var, x, cs_x, p, train, recs if save else None,
-                                          out=concat if last else None, cs_out=4 * self.chs, c_off=s * self.chs, packs=packs)
+                                          out=concat if last else None, cs_out=4 * self.chs, c_off=s * self.chs, packs=packs,
+                                          tracked=tracked, deferred=deferred if last else None)
             tape['streams'].append(recs)
             if not save:
                 del recs[:]
+        if deferred:
+            import ctypes
+            arr = lambda k: (ctypes.c_void_p * 4)(*[ptr(d[k]) for d in deferred])
+            call('mmlf_bn_apply_relu4', arr(0), cs_of(self.chs), self.chs, arr(1), arr(2), ptr(concat), 4 * self.chs,
+                 B, H, W, ptr(concat.absmax), _lib.stream_ptr())
+            del deferred[:]
         x, cs_x = concat, 4 * self.chs
         for spec in self.out_blocks:
-            x, cs_x = self._block_fwd(geo, spec, VAR_IDENTITY, x, cs_x, p, train, tape['out'] if save else None, packs=packs)
+            x, cs_x = self._block_fwd(geo, spec, VAR_IDENTITY, x, cs_x, p, train, tape['out'] if save else None, packs=packs,
+                                      tracked=tracked)
             if not save:
                 del tape['out'][:]
+        if tracked:
+            # the shared stream nets' counters appear twice: two forwards per pass, as in the reference
+            # (feed_forward.py:222-235 calls in_net_hv for h and v) -- one entry per tensor with its count, since a
+            # multi-tensor launch must not hold the same tensor twice
+            counts = {}
+            for t in tracked:
+                counts.setdefault(t.data_ptr(), [t, 0])[1] += 1
+            torch._foreach_add_([t for t, _ in counts.values()], [n for _, n in counts.values()])
         out = torch.empty((B, self.oc, H, W), dtype=torch.float32, device=dev)
         call('mmlf_unpack_nchw', ptr(x), cs_x, ptr(out), self.oc, B, H, W, _lib.stream_ptr())
         return out, (tape if save else None)

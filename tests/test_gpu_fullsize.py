@@ -257,7 +257,7 @@ def test_fused_batchnorm_statistics_bs512_vs_float64(C):
     torch.testing.assert_close(c[2 * C:3 * C].double(), mean, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(c[3 * C:].double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-6, atol=0)
     torch.testing.assert_close(rv.double(), var * n / (n - 1), rtol=2e-6, atol=0)      # momentum 1: the unbiased batch variance
-    assert torch.equal(z.absmax, geo.amax_of(z, cs))
+    assert torch.equal(geo.amax_canonical(z.absmax), geo.amax_of(z, cs))
 
 
 def test_upr_train_forward_and_loss_bs512_vs_stock_torch_ops():

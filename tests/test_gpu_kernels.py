@@ -178,6 +178,43 @@ def test_conv_backward(oracle, cin, cout, pad, variant, mode, monkeypatch):
     np.testing.assert_allclose(got, gin, rtol=2e-5, atol=2e-5 * max(1.0, np.abs(gin).max()))
 
 
+@pytest.mark.parametrize('C,B,H,W', [(70, 3, 10, 14), (70, 2, 33, 139), (6, 1, 5, 6)])
+def test_batchnorm_apply_of_four_streams_equals_four_slice_passes(C, B, H, W):
+    """mmlf_bn_apply_relu4 (one pass writing whole rows of the concat buffer; reference feed_forward.py:266-267) against
+    four mmlf_bn_apply_relu slice passes: the same bits in every position (borders and slack rows included) and the same
+    amax array."""
+    import ctypes
+    from mmlf_amd import engine, _lib
+    from mmlf_amd._lib import call, ptr
+    dev = _dev()
+    geo = engine.Geometry(B, H, W)
+    cs, cs_y = engine.cs_of(C), 4 * C
+    gen = torch.Generator(device=dev).manual_seed(C + W)
+    zs, scs, shs = [], [], []
+    for k in range(4):
+        z = torch.randn((geo.alloc, cs), device=dev, generator=gen) * (k + 1)      # junk in border positions too
+        zs.append(z.reshape(-1))
+        scs.append(torch.rand(C, device=dev, generator=gen) + 0.5)
+        shs.append(torch.randn(C, device=dev, generator=gen))
+    ref = torch.full((geo.alloc * cs_y,), 7.0, device=dev)
+    ref_amax = torch.zeros(geo.amax_n, device=dev)
+    for k in range(4):
+        call('mmlf_bn_apply_relu', ptr(zs[k]), cs, C, ptr(scs[k]), ptr(shs[k]), ptr(ref), cs_y, k * C, C, B, H, W,
+             ptr(ref_amax), _lib.stream_ptr())
+    got = torch.full((geo.alloc * cs_y,), 7.0, device=dev)
+    amax = torch.zeros(geo.amax_n, device=dev)
+    arr = lambda ts: (ctypes.c_void_p * 4)(*[ptr(t) for t in ts])
+    call('mmlf_bn_apply_relu4', arr(zs), cs, C, arr(scs), arr(shs), ptr(got), cs_y, B, H, W, ptr(amax), _lib.stream_ptr())
+    assert torch.equal(got, ref)
+    assert torch.equal(amax, ref_amax)              # (row r raises shard r % 64 in both forms)
+    assert float(amax[:geo.amax_head].max()) > 0
+    # argument checks: odd channel count, a row stride that is not 4 * C
+    with pytest.raises(RuntimeError):
+        call('mmlf_bn_apply_relu4', arr(zs), cs, C - 1, arr(scs), arr(shs), ptr(got), cs_y, B, H, W, None, _lib.stream_ptr())
+    with pytest.raises(RuntimeError):
+        call('mmlf_bn_apply_relu4', arr(zs), cs, C, arr(scs), arr(shs), ptr(got), cs_y + 8, B, H, W, None, _lib.stream_ptr())
+
+
 @pytest.mark.parametrize('C,cs_y,c_off', [(70, 72, 0), (70, 280, 70), (70, 280, 210), (280, 280, 0), (8, 32, 24)])
 def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
     from mmlf_amd import engine, _lib
@@ -212,10 +249,13 @@ def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
     full = y.cpu().numpy().reshape(geo.alloc, cs_y)
     got, g = nchw_from_grid(full.reshape(-1), cs_y, cs_y, geo, H, W, 1)
     # the amax array the f16 split scales by: max |y| of the tensor, then of every grid row
-    assert float(amax[0]) == float(got[:, c_off:c_off + C].max())
+    hd = geo.amax_head                  # 64 shards of the tensor maximum, then the rows
+    assert float(amax[:hd].max()) == float(got[:, c_off:c_off + C].max())
     rows = np.abs(g[..., c_off:c_off + C]).max(axis=(2, 3)).reshape(-1)
-    np.testing.assert_array_equal(amax[1:1 + rows.size].cpu().numpy(), rows)
-    assert not amax[1 + rows.size:].any()
+    np.testing.assert_array_equal(amax[hd:hd + rows.size].cpu().numpy(), rows)
+    assert not amax[hd + rows.size:].any()
+    shards = amax[:hd].cpu().numpy().reshape(-1, geo.amax_stride)
+    assert not shards[:, 1:].any() and np.count_nonzero(shards[:, 0]) > 1       # spread over slots 256 bytes apart
     np.testing.assert_allclose(got[:, c_off:c_off + C], y_ref, rtol=1e-5, atol=2e-6)
     assert (g[:, 0, :, c_off:c_off + C] == 0).all() and (g[:, :, 0, c_off:c_off + C] == 0).all()
     other = np.delete(full[:geo.NQ], np.s_[c_off:c_off + c_store], axis=1)
@@ -244,7 +284,7 @@ def test_batchnorm_train_eval_and_backward(oracle, C, cs_y, c_off):
     amax.zero_()
     call('mmlf_bn_bwd_apply', ptr(gyg), cs_y, c_off, ptr(zg), cs, C, ptr(coef), ptr(coef[C:]), ptr(coef[2 * C:]),
          ptr(k), ptr(dz), cs, B, H, W, ptr(amax), _lib.stream_ptr())
-    assert torch.equal(amax, geo.amax_of(dz, cs))
+    assert torch.equal(geo.amax_canonical(amax), geo.amax_of(dz, cs))
     np.testing.assert_allclose(dgam.cpu().numpy() - 1, gg_ref, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(dbet.cpu().numpy() - 1, gb_ref, rtol=1e-4, atol=1e-4)
     got, g = nchw_from_grid(dz.cpu().numpy(), cs, C, geo, H, W, 1)
@@ -267,8 +307,8 @@ def test_pack_unpack_roundtrip(C, cs, W):
     g[geo.NQ * cs:] = 0
     amax = torch.zeros(geo.amax_n, device=dev)
     call('mmlf_pack_nchw', ptr(xd), C, ptr(g), cs, B, H, W, ptr(amax), _lib.stream_ptr())
-    assert float(amax[0]) == float(np.abs(x).max())
-    assert torch.equal(amax, geo.amax_of(g, cs))
+    assert float(amax[:geo.amax_head].max()) == float(np.abs(x).max())
+    assert torch.equal(geo.amax_canonical(amax), geo.amax_of(g, cs))
     np.testing.assert_array_equal(g.cpu().numpy(), grid_from_nchw(x, cs, geo))
     back = torch.empty((B, C, H, W), device=dev)
     call('mmlf_unpack_nchw', ptr(g), cs, ptr(back), C, B, H, W, _lib.stream_ptr())
@@ -418,7 +458,7 @@ def test_fused_batchnorm_statistics_match_the_two_pass_form(cin, cout):
         out[mode] = (c.cpu().numpy(), rm.cpu().numpy(), rv.cpu().numpy())
     for a, b in zip(out['fused'], out['two_pass']):
         np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7)
-    assert torch.equal(z.absmax, geo.amax_of(z, cs_out))      # the conv epilogue's tensor and grid-row maxima (P >= 32: exact)
+    assert torch.equal(geo.amax_canonical(z.absmax), geo.amax_of(z, cs_out))      # the conv epilogue's tensor and grid-row maxima (P >= 32: exact)
 
 
 def test_slack_and_amax_zeroing():
@@ -427,7 +467,7 @@ def test_slack_and_amax_zeroing():
     dev = _dev()
     B, H, W, cs = 3, 5, 7, 8
     geo = engine.Geometry(B, H, W)
-    assert geo.amax_n >= 1 + B * geo.R
+    assert geo.amax_n >= geo.amax_head + B * geo.R
     buf = torch.full((geo.alloc * cs,), 3.0, device=dev)
     amax = torch.full((geo.amax_n + 3,), 5.0, device=dev)
     call('mmlf_zero_slack', ptr(buf), cs, B, H, W, ptr(amax), _lib.stream_ptr())
@@ -473,7 +513,7 @@ def test_relu_bit_mask_replaces_the_activation_reference(cin, cout):
     engine.conv(geo, dz, cs_mid, cout, pk, None, cout, a, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
     engine.conv(geo, dz, cs_mid, cout, pk, None, cout, b, cs_mid, 0, H + 1, W + 1, False, mask_in=mask)
     assert torch.equal(a, b)
-    assert torch.equal(a.absmax, b.absmax)
+    assert torch.equal(geo.amax_canonical(a.absmax), geo.amax_canonical(b.absmax))
     assert float(a.abs().max()) > 0
 
 
@@ -514,7 +554,7 @@ def test_thin_convolution_and_weight_gradient(oracle, cin, cout, pad, variant):
     g2 = g.copy()
     g2[:, ooff:ooff + oh, ooff:ooff + ow, :cout] = 0
     assert not g2.any() and np.isfinite(full[:geo.NQ]).all()          # zero border and pad channels, everything written
-    assert torch.equal(out.absmax, geo.amax_of(torch.nan_to_num(out), cs_out))
+    assert torch.equal(geo.amax_canonical(out.absmax), geo.amax_of(torch.nan_to_num(out), cs_out))
     # the engine routes this shape to the thin kernel in every conv mode
     out2 = geo.buf(cs_out, dev)
     engine.conv(geo, xg, cs_in, cin, None, tb, cout, out2, cs_out, shift, oh, ow, True, w_master=tw, variant=variant)
@@ -571,7 +611,8 @@ def test_register_streamed_conv_on_wide_pitch(oracle, cin, pad):
         g2[:, ooff:ooff + oh, ooff:ooff + ow, :cout] = 0
         assert not g2.any()
         true = geo.amax_of(out, cs_out)
-        assert float(out.absmax[0]) == float(true[0]) and bool((out.absmax >= true).all())
+        got_amax = geo.amax_canonical(out.absmax)
+        assert float(got_amax[0]) == float(true[0]) and bool((got_amax >= true).all())
         if relu:
             bits = int(np.unpackbits(mask.cpu().numpy().view(np.uint8)).sum())
             assert bits == int((got > 0).sum())                      # one bit per positive stored output
@@ -622,7 +663,7 @@ g = geo.buf(cs, dev)
 engine.conv(geo, z, cs, cout, engine.pack_filter(w, 0, True), None, cin, g, cs, 0, H + 1, W + 1, False, mask_in=mask)
 torch.cuda.synchronize()
 np.savez(sys.argv[1], y=y.cpu().numpy(), z=z.cpu().numpy(), g=g.cpu().numpy(), mask=mask.cpu().numpy(),
-         ay=y.absmax.cpu().numpy(), az=z.absmax.cpu().numpy(), part=part.cpu().numpy())
+         ay=geo.amax_canonical(y.absmax).cpu().numpy(), az=geo.amax_canonical(z.absmax).cpu().numpy(), part=part.cpu().numpy())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for rs_on, nw in (('0', '0'), ('0', '1'), ('1', '1')):
