@@ -446,6 +446,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
 #pragma unroll
         for (int k = 0; k < 8; ++k) a.relu_mask_out[mbase + 64 * k] = mw[k];
     }
+#ifndef MMLF_ABL_NO_CONV_AMAX      // timing ablation (tools/build_variant.sh): no row maxima from the conv epilogue
     if (a.out_amax) {
         const unsigned d0 = (unsigned)qb;                       // first destination position of the wave
         const unsigned rd0 = fastdiv(d0, a.divP);
@@ -468,6 +469,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
             run_max = fmaxf(run_max, fmaxf(m_lo, m_hi));        // lane 0 carries the tensor maximum
         }
     }
+#endif
 }
 
 // f16 split: the power-of-two scale wave w of tile Q0 applies to its activation operand.  The wave's valid
@@ -1982,16 +1984,23 @@ extern "C" int64_t mmlf_packed_filter_floats(int K, int N)
 // split-arithmetic kernel configuration for a layer: MB 16-row blocks of input channels (+ ones row) per
 // slice, NB 16-column blocks of output channels, and the (slice x position-split) grid
 struct Wgrad16Cfg { int mb, nb, nslice, nsplit; };
-static inline bool wgrad16_cfg(int Cin, int Cout, Wgrad16Cfg *c)
+// nchunks: 32-position chunks of the launch, or -1 for the largest layout (workspace sizing)
+static inline bool wgrad16_cfg(int Cin, int Cout, long long nchunks, Wgrad16Cfg *c)
 {
     if (Cout <= 0 || Cout > 288) return false;
     c->nb = Cout <= 32 ? 2 : Cout <= 80 ? 5 : Cout <= 128 ? 8 : 18;
     if (c->nb == 18) {           // wgrad4tap_x6w_kernel: one 512-thread workgroup per CU, three even rounds
         c->mb = 3;
         c->nslice = (Cin + 1 + 47) / 48;
-        c->nsplit = 256 / c->nslice;     // ONE round on 256 CUs (252 workgroups at six slices)
+        // Small batches: ONE round on 256 CUs (42 splits = 252 workgroups at six slices; a third of the partial sums to
+        // write and reduce: -2...-4 % per launch at 64 patches, +0.9 % per 64-patch step).  From ~150 patches on, three
+        // even rounds of 256 (128 splits) are 0.8 % faster inside the step (profiles/r04_wgrad_nsplit.log).
+        const int one_round = 256 / c->nslice, three_rounds = (768 / c->nslice + 7) / 8 * 8;
+        c->nsplit = nchunks < 0 ? (one_round > three_rounds ? one_round : three_rounds)
+                                : (nchunks >= 42 * 1024 ? three_rounds : one_round);
         static const int forced = [] { const char *e = getenv("MMLF_WGRAD_NSPLIT"); return e ? atoi(e) : 0; }();
-        if (forced > 0) c->nsplit = forced;                      // A/B switch (tools/ab_env.sh)
+        if (forced > 0 && nchunks >= 0)                          // A/B switch (tools/ab_env.sh), inside the sized workspace
+            c->nsplit = forced < three_rounds || forced < one_round ? forced : c->nsplit;
         if (c->nsplit < 8) c->nsplit = 8;
     } else {                     // wgrad4tap_x6n_kernel: two 256-thread workgroups per CU
         c->mb = (c->nb <= 5 && Cin + 1 > 32 && Cin + 1 <= 80) ? 5 : 2;
@@ -2009,7 +2018,7 @@ static int64_t wgrad_partial_floats(int Cin, int Cout)
     const int nslice = (Cin + 1 + 31) / 32;
     int64_t n = (int64_t)wgrad_nsplit(nslice) * 4 * (nslice * 32) * (nt * 32);          // exact-f32 kernel
     Wgrad16Cfg c;
-    if (wgrad16_cfg(Cin, Cout, &c)) {                                                    // split kernel
+    if (wgrad16_cfg(Cin, Cout, -1, &c)) {                                                // split kernel
         const int64_t m = (int64_t)c.nsplit * 4 * (c.nslice * 16 * c.mb) * (16 * c.nb);
         if (m > n) n = m;
     }
@@ -2196,7 +2205,7 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
         hipLaunchKernelGGL(wgrad_chunk_scales_kernel, dim3((a.nchunks + 255) / 256), dim3(256), 0, st, ca);
         a.chunk_scales = ca.out;
     }
-    if (planes && wgrad16_cfg(Cin, Cout, &c)) {
+    if (planes && wgrad16_cfg(Cin, Cout, a.nchunks, &c)) {
         a.nslice = c.nslice;
         a.nsplit = c.nsplit;
         a.chunks_per_split = (a.nchunks + a.nsplit - 1) / a.nsplit;
