@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(BnApply4 s, int cs_z, in
 // DESIGN.md section 4.8, profiles/r04_bn_bench_*.log, r04_ab_bench_bn*.log; the code is in the history: commit 5c543cc.)
 
 // NCHW <-> grid
-#define PACK_XT 128   // positions per transpose tile of pack_nchw_kernel (halved until the tile fits 64 KB: wide tensors)
+#define PACK_XT 128   // positions per transpose tile of pack_nchw_kernel (halved until the tile fits 32 KB: wide tensors;
+                      // at 64 KB two workgroups per CU packed the 108-channel DPP gradient 0.5 ms slower)
 __global__ __launch_bounds__(256) void pack_nchw_kernel(const float *__restrict__ src, int C,
                                                         float *__restrict__ grid, int cs, int H, int W,
                                                         float *__restrict__ amax, int xt)
@@ -393,16 +394,29 @@ __global__ __launch_bounds__(256) void pack_nchw_kernel(const float *__restrict_
 }
 
 __global__ __launch_bounds__(256) void unpack_nchw_kernel(const float *__restrict__ grid, int cs,
-                                                          float *__restrict__ dst, int C, int H, int W)
+                                                          float *__restrict__ dst, int C, int H, int W, int xt)
 {
+    // the inverse transpose, through LDS as well: the grid row is read with the channels across the lanes (whole position
+    // rows), the NCHW planes are written with x across the lanes.  (One thread per (c, x) straight from the grid read
+    // with a stride of cs floats between lanes: 1.7 TB/s on the 108-channel DPP scores; 2.3 -> 0.9 ms per launch.)
+    extern __shared__ float tile[];            // [xt][C | 1]: position-major, odd pitch (conflict-free both ways)
     const int P = W + 2, R = H + 2;
     const int row = blockIdx.x;  // b*H + (y-1)
     const int b = row / H, y = row - b * H + 1;
     const size_t base = ((size_t)(b * R + y)) * P;
-    const int total = W * C;
-    for (int e = threadIdx.x; e < total; e += blockDim.x) {
-        const int c = e / W, x = e - c * W;
-        dst[(((size_t)b * C + c) * H + (y - 1)) * W + x] = grid[(base + x + 1) * cs + c];
+    const int pitch = C | 1;
+    for (int x0 = 0; x0 < W; x0 += xt) {
+        const int nx = min(xt, W - x0);
+        for (int e = threadIdx.x; e < nx * C; e += blockDim.x) {
+            const int xl = e / C, c = e - xl * C;
+            tile[xl * pitch + c] = grid[(base + x0 + xl + 1) * cs + c];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < C * nx; e += blockDim.x) {
+            const int c = e / nx, xl = e - c * nx;
+            dst[(((size_t)b * C + c) * H + (y - 1)) * W + x0 + xl] = tile[xl * pitch + c];
+        }
+        __syncthreads();
     }
 }
 
@@ -1201,7 +1215,8 @@ extern "C" int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int
 {
     MMLF_CHECK_ARG(nchw && grid && C > 0 && cs % 4 == 0 && C <= cs, "mmlf_pack_nchw: C=%d cs=%d", C, cs);
     int xt = PACK_XT;            // DPP with many views packs a gradient of 4*views*3 channels (132 at 11 views)
-    while (xt > 4 && (size_t)cs * (xt | 1) * sizeof(float) > 64 * 1024) xt >>= 1;
+    static const size_t tile_limit = [] { const char *e = getenv("MMLF_PACK_LDS_KB"); return (size_t)(e ? atoi(e) : 32) * 1024; }();
+    while (xt > 4 && (size_t)cs * (xt | 1) * sizeof(float) > tile_limit) xt >>= 1;
     const size_t lds = (size_t)cs * (xt | 1) * sizeof(float);
     MMLF_CHECK_ARG(lds <= 64 * 1024, "mmlf_pack_nchw: cs=%d does not fit the transpose tile", cs);
     hipLaunchKernelGGL(pack_nchw_kernel, dim3(B * (H + 2)), dim3(256), lds, (hipStream_t)stream, nchw, C, grid, cs, H, W,
@@ -1270,7 +1285,10 @@ extern "C" int mmlf_zero_slack4(float *const grid[4], const int cs[4], float *co
 extern "C" int mmlf_unpack_nchw(const float *grid, int cs, float *nchw, int C, int B, int H, int W, void *stream)
 {
     MMLF_CHECK_ARG(nchw && grid && C > 0 && C <= cs, "mmlf_unpack_nchw: C=%d cs=%d", C, cs);
-    hipLaunchKernelGGL(unpack_nchw_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, grid, cs, nchw, C, H, W);
+    int xt = 32;
+    while (xt > 1 && (size_t)xt * (C | 1) * sizeof(float) > 32 * 1024) xt >>= 1;
+    hipLaunchKernelGGL(unpack_nchw_kernel, dim3(B * H), dim3(256), (size_t)xt * (C | 1) * sizeof(float), (hipStream_t)stream,
+                       grid, cs, nchw, C, H, W, xt);
     return mmlf_launch_status("mmlf_unpack_nchw");
 }
 
