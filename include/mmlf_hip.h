@@ -100,6 +100,8 @@ int mmlf_conv2x2_split(const float *in, int cs_in, int K, const void *packed, co
  * with the buffer's slack, before the tensor's first producer.
  * `packed` holds mmlf_packed_filter_h2_bytes(K, N) bytes (the columns' 1/scale factors sit behind the planes). */
 int64_t mmlf_amax_entries(int B, int H, int W);
+int mmlf_grid_pad_w(void);    /* grid pitch P = W + pad_w (2; a build option of the library, so the binding asks) */
+int mmlf_grid_pad_h(void);    /* grid rows per image R = H + pad_h (2) */
 int mmlf_amax_head(void);
 int mmlf_amax_shard_stride(void);
 int64_t mmlf_packed_filter_h2_bytes(int K, int N);

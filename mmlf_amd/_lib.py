@@ -30,6 +30,8 @@ SIGNATURES = {
     'mmlf_conv2x2_wgrad_h2': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'mmlf_packed_filter_h2_bytes': (_i64, [_i, _i]),
     'mmlf_amax_entries': (_i64, [_i, _i, _i]),
+    'mmlf_grid_pad_w': (_i, []),
+    'mmlf_grid_pad_h': (_i, []),
     'mmlf_amax_head': (_i, []),
     'mmlf_amax_shard_stride': (_i, []),
     'mmlf_pack_filter_h2': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

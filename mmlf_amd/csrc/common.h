@@ -50,6 +50,23 @@ struct PerDeviceOnce {
 };
 
 // Padded-grid geometry of one launch (see include/mmlf_hip.h).
+// Columns / rows a patch's grid has beyond its image: 2 and 2, a zero column and row of its own on every side.  The flat
+// index wraps, so the zero column in front of a row could double as the one behind the previous row (pitch W + 1) and the
+// zero row in front of a patch as the one behind the previous patch (H + 1 rows): every kernel takes P and R from
+// make_grid, and both COMPACT forms were built and measured in round 4 (-DMMLF_GRID_PAD_W=1 [-DMMLF_GRID_PAD_H=1]):
+//  * H + 1 rows: the kernel tests pass, but the LAST image row of a patch then shares its 32-position wave -- and its operand
+//    scale -- with the first row of the next patch: "a small patch beside a large one keeps float32-level precision" is lost
+//    for up to 31 positions per patch (test_conv_patches_of_very_different_magnitude fails);
+//  * pitch W + 1 alone (9 506 instead of 9 604 positions per 96 x 96 patch): same-box A/B 458.9-459.7 ms against 458.9-461.0 per
+//    bs=512 step, wide conv 7.54-7.57 against 7.54-7.59 ms per launch, wide weight gradient -0.8 %
+//    (profiles/r04_ab_grid_pitch.log): the 1 % of positions does not show, and two statistical precision bars move
+//    (one tensor of the gradient yardstick 3.1 -> 4.5 with median and 90th percentile improved).  Not adopted.
+#ifndef MMLF_GRID_PAD_W
+#define MMLF_GRID_PAD_W 2
+#endif
+#ifndef MMLF_GRID_PAD_H
+#define MMLF_GRID_PAD_H 2
+#endif
 struct Grid {
     int B, H, W, P, R, G;
     long long NQ, NQpad;
@@ -59,7 +76,7 @@ static inline Grid make_grid(int B, int H, int W)
 {
     Grid g;
     g.B = B; g.H = H; g.W = W;
-    g.P = W + 2; g.R = H + 2; g.G = g.P * g.R;
+    g.P = W + MMLF_GRID_PAD_W; g.R = H + MMLF_GRID_PAD_H; g.G = g.P * g.R;
     g.NQ = (long long)B * g.G;
     g.NQpad = (g.NQ + MMLF_TILE_MAX - 1) / MMLF_TILE_MAX * MMLF_TILE_MAX;
     return g;

@@ -13,6 +13,8 @@ extern "C" int64_t mmlf_amax_entries(int B, int H, int W)
     if (B <= 0 || H <= 0 || W <= 0) return -1;
     return amax_entries(make_grid(B, H, W));
 }
+extern "C" int mmlf_grid_pad_w(void) { return MMLF_GRID_PAD_W; }
+extern "C" int mmlf_grid_pad_h(void) { return MMLF_GRID_PAD_H; }
 extern "C" int mmlf_amax_head(void) { return MMLF_AMAX_HEAD; }
 extern "C" int mmlf_amax_shard_stride(void) { return MMLF_AMAX_SHARD_STRIDE; }
 extern "C" int64_t mmlf_grid_alloc_positions(int B, int H, int W)
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
                                                         const float *__restrict__ invstd, int C,
                                                         double *__restrict__ partial, int B, int H, int W)
 {
-    const int P = W + 2, R = H + 2;
+    const int P = W + MMLF_GRID_PAD_W, R = H + MMLF_GRID_PAD_H;
     const int cvn = (C + V - 1) / V;            // channel groups that hold real channels
     const int ppi = 256 / cvn;                  // positions per iteration
     const int tid = threadIdx.x;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void bn_rows_kernel(const float *__restrict__ 
     // Per-channel coefficients sit in LDS.  (Quarter rows per block -- 8 % faster stand-alone at 64 patches, where whole
     // rows leave a tail of blocks on an empty chip -- cost 4 ms per 60 ms step inside it: profiles/r04_ab64_bn_row_segments.log.)
     extern __shared__ float coefs[];           // [5][Cpad]: scale, shift, (mean, k1, k2, k3 for MODE 1)
-    const int P = W + 2, R = H + 2;
+    const int P = W + MMLF_GRID_PAD_W, R = H + MMLF_GRID_PAD_H;
     const int cvn = (C_store + V - 1) / V;
     const int Cpad = cvn * V;
     for (int c = threadIdx.x; c < Cpad; c += blockDim.x) {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(BnApply4 s, int cs_z, in
                                                         int H, int W, float *__restrict__ amax, int nrows)
 {
     extern __shared__ float coefs[];           // [2][4 * C]: scale, shift in concat order
-    const int P = W + 2, R = H + 2;
+    const int P = W + MMLF_GRID_PAD_W, R = H + MMLF_GRID_PAD_H;
     const int C4 = 4 * C, half = C / 2, cvn = 2 * C;     // channel pairs per position row
     for (int c = threadIdx.x; c < C4; c += blockDim.x) {
         const int k = c / C, cl = c - k * C;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void pack_nchw_kernel(const float *__restrict_
     // groups across the lanes (whole 16*c4n-byte position rows per instruction instead of one 16-byte piece per line)
     extern __shared__ float tile[];            // [cs][xt | 1]: channel-major, odd pitch (conflict-free both ways)
     float mx = 0.f;
-    const int P = W + 2, R = H + 2;
+    const int P = W + MMLF_GRID_PAD_W, R = H + MMLF_GRID_PAD_H;
     const int row = blockIdx.x;
     const int b = row / R, y = row - b * R;
     const size_t base = (size_t)row * P;
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void unpack_nchw_kernel(const float *__restric
     // rows), the NCHW planes are written with x across the lanes.  (One thread per (c, x) straight from the grid read
     // with a stride of cs floats between lanes: 1.7 TB/s on the 108-channel DPP scores; 2.3 -> 0.9 ms per launch.)
     extern __shared__ float tile[];            // [xt][C | 1]: position-major, odd pitch (conflict-free both ways)
-    const int P = W + 2, R = H + 2;
+    const int P = W + MMLF_GRID_PAD_W, R = H + MMLF_GRID_PAD_H;
     const int row = blockIdx.x;  // b*H + (y-1)
     const int b = row / H, y = row - b * H + 1;
     const size_t base = ((size_t)(b * R + y)) * P;
@@ -1154,7 +1156,7 @@ extern "C" int mmlf_bn_apply_relu(const float *z, int cs_z, int C, const float *
     MMLF_CHECK_ARG(cs_z % 4 == 0 && cs_y % 2 == 0 && c_off % 2 == 0 && C <= cs_z && C_store >= C &&
                        c_off + C_store <= cs_y,
                    "mmlf_bn_apply_relu: C=%d cs_z=%d cs_y=%d c_off=%d C_store=%d", C, cs_z, cs_y, c_off, C_store);
-    const int nrows = B * (H + 2);
+    const int nrows = B * (H + MMLF_GRID_PAD_H);
     hipLaunchKernelGGL((bn_rows_kernel<0, 4>), dim3(nrows), dim3(256), 6 * (C_store + 4) * sizeof(float), (hipStream_t)stream, z, cs_z,
                        nullptr, 0, 0, scale, shift, nullptr, nullptr, C, y, cs_y, c_off, C_store, H, W, amax_out, nrows);
     return mmlf_launch_status("mmlf_bn_apply_relu");
@@ -1172,7 +1174,7 @@ extern "C" int mmlf_bn_apply_relu4(const float *const z[4], int cs_z, int C, con
         MMLF_CHECK_ARG(z[k] && scale[k] && shift[k], "mmlf_bn_apply_relu4: null pointer in source %d", k);
         s.z[k] = z[k]; s.scale[k] = scale[k]; s.shift[k] = shift[k];
     }
-    const int nrows = B * (H + 2);
+    const int nrows = B * (H + MMLF_GRID_PAD_H);
     hipLaunchKernelGGL(bn_apply4_kernel, dim3(nrows), dim3(256), 8 * C * sizeof(float), (hipStream_t)stream, s, cs_z, C,
                        y, H, W, amax_out, nrows);
     return mmlf_launch_status("mmlf_bn_apply_relu4");
@@ -1204,7 +1206,7 @@ extern "C" int mmlf_bn_bwd_apply(const float *gy, int cs_gy, int c_off, const fl
     MMLF_CHECK_ARG(gy && z && scale && shift && save_mean && coef && dz, "mmlf_bn_bwd_apply: null pointer");
     MMLF_CHECK_ARG(cs_gy % 2 == 0 && c_off % 2 == 0 && cs_z % 4 == 0 && cs_dz % 4 == 0 && C <= cs_dz,
                    "mmlf_bn_bwd_apply: layout");
-    const int nrows = B * (H + 2);
+    const int nrows = B * (H + MMLF_GRID_PAD_H);
     hipLaunchKernelGGL((bn_rows_kernel<1, 4>), dim3(nrows), dim3(256), 6 * (cs_dz + 4) * sizeof(float), (hipStream_t)stream, z, cs_z, gy,
                        cs_gy, c_off, scale, shift, save_mean, coef, C, dz, cs_dz, 0, cs_dz, H, W, amax_out, nrows);
     return mmlf_launch_status("mmlf_bn_bwd_apply");
@@ -1219,7 +1221,7 @@ extern "C" int mmlf_pack_nchw(const float *nchw, int C, float *grid, int cs, int
     while (xt > 4 && (size_t)cs * (xt | 1) * sizeof(float) > tile_limit) xt >>= 1;
     const size_t lds = (size_t)cs * (xt | 1) * sizeof(float);
     MMLF_CHECK_ARG(lds <= 64 * 1024, "mmlf_pack_nchw: cs=%d does not fit the transpose tile", cs);
-    hipLaunchKernelGGL(pack_nchw_kernel, dim3(B * (H + 2)), dim3(256), lds, (hipStream_t)stream, nchw, C, grid, cs, H, W,
+    hipLaunchKernelGGL(pack_nchw_kernel, dim3(B * (H + MMLF_GRID_PAD_H)), dim3(256), lds, (hipStream_t)stream, nchw, C, grid, cs, H, W,
                        amax_out, xt);
     return mmlf_launch_status("mmlf_pack_nchw");
 }

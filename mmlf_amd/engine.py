@@ -26,7 +26,8 @@ def cs_of(c):
 class Geometry:
     def __init__(self, B, H, W):
         self.B, self.H, self.W = B, H, W
-        self.P, self.R = W + 2, H + 2
+        # pitch W + 2, H + 2 rows (the library's build options MMLF_GRID_PAD_W / _H: csrc/common.h has the measured alternatives)
+        self.P, self.R = W + int(_lib.load().mmlf_grid_pad_w()), H + int(_lib.load().mmlf_grid_pad_h())
         self.G = self.P * self.R
         self.NQ = B * self.G
         self.alloc = int(_lib.load().mmlf_grid_alloc_positions(B, H, W))
