@@ -75,5 +75,21 @@ def run(cin, cout):
         print(f'{TAG} {cin}->{cout} B={B} {k:14s} median {med:8.3f} ms  min {mn:8.3f} ms  {fl / med / 1e9:7.1f} TFLOP/s', flush=True)
 
 
+def run_wgrad(cin, cout):
+    """weight gradient of a pad-1 convolution cin -> cout alone (shapes with cin != cout: the DPP head)"""
+    cs_in, cs_out = engine.cs_of(cin), engine.cs_of(cout)
+    x = grid_rand(cs_in, cin, H, W, 1, relu=True)
+    g1 = grid_rand(cs_out, cout, H + 1, W + 1, 0)
+    gw, gb = torch.zeros(cout, cin, 2, 2, device=dev), torch.zeros(cout, device=dev)
+    wsb = engine._Workspace.get(dev).wgrad_ws(geo, cin, cout)
+    med, mn = timeit(lambda: engine.wgrad(geo, x, cs_in, cin, g1, cs_out, cout, 0, gw, gb, 0, wsb))
+    fl = 2.0 * B * (H + 1) * (W + 1) * cout * 4 * cin
+    print(f'{TAG} {cin}->{cout} B={B} wgrad_p1       median {med:8.3f} ms  min {mn:8.3f} ms  {fl / med / 1e9:7.1f} TFLOP/s', flush=True)
+
+
+if os.environ.get("KBENCH_SHAPES"):            # e.g. KBENCH_SHAPES=280x108,108x108 (the DPP head): weight gradients only
+    for sh in os.environ["KBENCH_SHAPES"].split(","):
+        run_wgrad(*[int(v) for v in sh.split("x")])
+    sys.exit(0)
 if os.environ.get("KBENCH_ONLY70", "0") == "0": run(280, 280)
 if os.environ.get("KBENCH_ONLY280", "0") == "0": run(70, 70)
