@@ -10,8 +10,10 @@ reference's downstream analysis scripts and the 4D light field benchmark evaluat
 The reference method lives on its dataset object and re-loads the scene from disk (``self.__getitem__(i)``); dataset
 disk IO is outside this build, so the scene-side arrays (gt, centre view, view stacks) are
 arguments here.  Every array may be a numpy array or a torch tensor on any device (``Ensamble`` / ``FeedForward``
-outputs go straight in).  PNGs follow reference dl.py:77-106 (min-max normalise when outside [0, 1], 8 bit); they
-are written with PIL -- the reference's skimage is not installed in this image, so they are not pinned by a fixture.
+outputs go straight in).  PNGs follow reference dl.py:77-106 (min-max normalise when outside [0, 1], 8 bit) and
+skimage.img_as_ubyte's float rule (x * 255 in the image's own float type, nearest even, clipped); they are written with
+PIL -- the reference's skimage is not installed in this image, so the PNG bytes are not pinned by a fixture; the decoded
+PIXELS are checked against a restatement of those two rules (tests/test_results_io.py).
 """
 import os
 
@@ -31,13 +33,18 @@ def _np(x):
 def save_img(fname, arr):
     """reference dl.py:77-106: (3, h, w) rgb or (h, w) grey, normalised to [0, 1] if it leaves that range"""
     from PIL import Image
-    arr = _np(arr).astype(np.float64)
+    arr = _np(arr)
+    if not np.issubdtype(arr.dtype, np.floating):
+        arr = arr.astype(np.float64)
+    # the arithmetic stays in the array's own float type, as in the reference (float32 maps normalise and scale in
+    # float32: a pixel that sits on a rounding tie comes out the same)
     a_min, a_max = np.min(arr), np.max(arr)
     if a_min < 0.0 or a_max > 1.0:
         arr = (arr - a_min) / (a_max - a_min)
     if arr.ndim == 3:
         arr = np.transpose(arr, (1, 2, 0))
-    img = np.clip(np.rint(arr * 255.0), 0, 255).astype(np.uint8)      # skimage.img_as_ubyte on [0, 1] floats
+    # skimage.img_as_ubyte on [0, 1] floats: multiply by 255 in the input's float type, round to nearest even, clip
+    img = np.clip(np.rint(np.multiply(arr, 255, dtype=arr.dtype)), 0, 255).astype(np.uint8)
     Image.fromarray(img).save(fname)
 
 

@@ -56,6 +56,48 @@ def _check_layout(root, names, gt, result, uncert, gmm, nll, posterior, runtime)
         assert open(os.path.join(root, 'ours', 'runtimes', f'{scene}.txt')).read() == str(runtime / len(names))
         for png in ('gt.png', 'diff.png', 'result.png', 'uncert.png', 'center.png', 'view_h_0.png', 'view_d_2.png'):
             assert os.path.getsize(os.path.join(sd, png)) > 0
+        # pixel values (the PNG container is the encoder's business): reference dl.py:93-106 + skimage.img_as_ubyte
+        lo, hi = gt[b].min(), gt[b].max()
+        for png, src in (('gt.png', gt[b]), ('diff.png', np.abs(gt[b] - result[b])), ('uncert.png', uncert[b]),
+                         ('result.png', np.clip((result[b] - lo) / (hi - lo), 0.0, 1.0))):
+            np.testing.assert_array_equal(_png_pixels(os.path.join(sd, png)), _ubyte_like_the_reference(src), err_msg=png)
+
+
+def _png_pixels(fname):
+    from PIL import Image
+    return np.asarray(Image.open(fname))
+
+
+def _ubyte_like_the_reference(arr):
+    """dl.py:93-103 (min-max normalise when the array leaves [0, 1], CHW -> HWC) followed by skimage.img_as_ubyte on a
+    float image: x * 255 in the image's own float type, rounded to nearest even, clipped (skimage/util/dtype.py _convert)"""
+    a_min, a_max = np.min(arr), np.max(arr)
+    if a_min < 0.0 or a_max > 1.0:
+        arr = (arr - a_min) / (a_max - a_min)
+    if arr.ndim == 3:
+        arr = np.transpose(arr, (1, 2, 0))
+    out = np.multiply(arr, 255, dtype=arr.dtype)
+    np.rint(out, out=out)
+    np.clip(out, 0, 255, out=out)
+    return out.astype(np.uint8)
+
+
+def test_save_img_pixels_rgb_and_float32_ties(tmp_path):
+    """colour images go CHW -> HWC; float32 maps are scaled in float32 (a float64 detour moves pixels that sit on a tie)"""
+    rs = np.random.RandomState(11)
+    rgb = rs.rand(3, 9, 7).astype(np.float32)
+    fn = str(tmp_path / 'rgb.png')
+    results.save_img(fn, torch.from_numpy(rgb))
+    np.testing.assert_array_equal(_png_pixels(fn), _ubyte_like_the_reference(rgb))
+    # values whose product with 255 rounds differently in float32 and float64
+    k = np.arange(0, 255, dtype=np.float64) + 0.5
+    x = (k / 255.0).astype(np.float32).reshape(15, 17)
+    x[0, 0] = 0.0                                   # keeps the array inside [0, 1]: no normalisation
+    fn = str(tmp_path / 'ties.png')
+    results.save_img(fn, x)
+    want = _ubyte_like_the_reference(x)
+    np.testing.assert_array_equal(_png_pixels(fn), want)
+    assert (want != np.clip(np.rint(x.astype(np.float64) * 255.0), 0, 255).astype(np.uint8)).any()   # the case is not vacuous
 
 
 @pytest.mark.parametrize('dev', ['cpu', pytest.param('cuda', marks=pytest.mark.gpu)])
