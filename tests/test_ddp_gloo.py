@@ -1,4 +1,4 @@
-"""World-size-2 rehearsal of the data-parallel train step on CPU (gloo backend):
+"""World-size-2 and -4 rehearsal of the data-parallel train step on CPU (gloo backend):
 sharding, bucketed gradient all-reduce, global masked-mean loss, rank-0 buffer semantics."""
 import os
 import socket
@@ -12,6 +12,8 @@ from conftest import TINY_KW
 from mmlf_amd import synth
 from mmlf_amd.feed_forward import FeedForward
 from mmlf_amd.train import GradBuckets, TrainStep, flatten_parameters
+
+import pytest
 
 B, PS = 4, 16
 
@@ -30,9 +32,9 @@ def _make(seed=3, variant_kw=None):
     return m
 
 
-def _data():
-    stacks, gt, mask = synth.synth_inputs(B, PS, seed=6)
-    mask[0, :, :9] = 0          # unequal valid-pixel counts between the two shards
+def _data(world=2):
+    stacks, gt, mask = synth.synth_inputs(B * world // 2, PS, seed=6)      # two patches per rank
+    mask[0, :, :9] = 0          # unequal valid-pixel counts between the shards
     return [torch.from_numpy(s) for s in stacks], torch.from_numpy(gt), torch.from_numpy(mask)
 
 
@@ -43,8 +45,8 @@ def _worker(rank, world, port, out_dir):
     try:
         model = _make(seed=3 + rank)          # different weights per rank: the broadcast must fix that
         step = TrainStep(model, lr=1e-2, loss_margin=3)
-        stacks, gt, mask = _data()
-        lo, hi = rank * B // world, (rank + 1) * B // world
+        stacks, gt, mask = _data(world)
+        lo, hi = 2 * rank, 2 * rank + 2
         losses = []
         for it in (1, 2):
             losses.append(float(step(*[s[lo:hi].contiguous() for s in stacks], gt[lo:hi], mask[lo:hi], it)))
@@ -55,19 +57,21 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_manual_average(tmp_path):
+@pytest.mark.parametrize('world', [2, 4])
+def test_n_rank_step_equals_manual_average(tmp_path, world):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0 = torch.load(tmp_path / 'r0.pt')
-    r1 = torch.load(tmp_path / 'r1.pt')
-    assert torch.equal(r0['flat'], r1['flat'])                 # replicas stay in lock-step
-    for k in r0['bufs']:
-        assert torch.equal(r0['bufs'][k], r1['bufs'][k]), k   # rank 0's BN buffers win
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ranks = [torch.load(tmp_path / f'r{r}.pt') for r in range(world)]
+    r0, r1 = ranks[0], ranks[1]
+    for rk in ranks[1:]:
+        assert torch.equal(r0['flat'], rk['flat'])                 # replicas stay in lock-step
+        for k in r0['bufs']:
+            assert torch.equal(r0['bufs'][k], rk['bufs'][k]), k   # rank 0's BN buffers win
 
-    # single-process emulation: two replicas with replica-local BN statistics, gradients averaged,
+    # single-process emulation: `world` replicas with replica-local BN statistics, gradients averaged,
     # loss normalised by the GLOBAL mask count (reference computes the loss on the gathered batch)
-    stacks, gt, mask = _data()
-    replicas = [_make(seed=3), _make(seed=3)]
+    stacks, gt, mask = _data(world)
+    replicas = [_make(seed=3) for _ in range(world)]
     steps = [TrainStep(m, lr=1e-2, loss_margin=3) for m in replicas]
     margin = steps[0]._mask(mask)
     total = float(margin.sum())
@@ -76,23 +80,24 @@ def test_two_rank_step_equals_manual_average(tmp_path):
         for r, (m, st) in enumerate(zip(replicas, steps)):
             lo, hi = r * 2, r * 2 + 2
             st.grad.zero_()
-            den = torch.tensor([total / 2], dtype=torch.float64)
+            den = torch.tensor([total / world], dtype=torch.float64)
             losses.append(float(st._torch_fwd_bwd(*[s[lo:hi].contiguous() for s in stacks], gt[lo:hi],
                                                    margin[lo:hi], den)))
-        avg = (steps[0].grad + steps[1].grad) / 2
+        avg = sum(st.grad for st in steps) / world
         solid = avg.abs() > 1e-5 if it == 1 else solid & (avg.abs() > 1e-5)
         for st in steps:
             st.grad.copy_(avg)
             st.adam_steps += 1
             st._adam(st.current_lr(it), 1.0)
-        np.testing.assert_allclose(r0['losses'][it - 1], losses[0], rtol=1e-5)
+        for rk, want in zip(ranks, losses):
+            np.testing.assert_allclose(rk['losses'][it - 1], want, rtol=1e-5)
     # Adam turns rounding noise on exactly-zero gradients (conv biases in front of a train-mode BN)
     # into +-lr steps, so only elements with a solid gradient are comparable; the rest is bounded.
     torch.testing.assert_close(r0['flat'][solid], steps[0].flat[solid], rtol=1e-4, atol=2e-5)
     assert float((r0['flat'] - steps[0].flat).abs().max()) <= 2 * 2 * 1e-2 + 1e-6
     assert float(solid.float().mean()) > 0.9
     # the rank-averaged loss is the global masked mean
-    np.testing.assert_allclose((r0['losses'][0] + r1['losses'][0]) / 2,
+    np.testing.assert_allclose(sum(rk['losses'][0] for rk in ranks) / world,
                                (_global_loss(_make(seed=3), stacks, gt, margin)), rtol=0.2)
 
 
