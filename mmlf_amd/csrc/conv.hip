@@ -106,6 +106,9 @@ __device__ __forceinline__ void mmlf_set_prio(int level)
 #ifndef MMLF_ABL_NOEARLY
 #define MMLF_ABL_NOEARLY 0     // 1: no early barrier / next-chunk fragment prefetch (the registers a 4-row-block wave cannot spare)
 #endif
+#ifndef MMLF_DMA_A_NT
+#define MMLF_DMA_A_NT 0        // 1: the split-precision conv kernels fetch their ACTIVATION pieces with the non-temporal policy (A/B)
+#endif
 #ifndef MMLF_RING16
 #define MMLF_RING16 3   // pipeline depth of the sixteen-wave conv variant (LDS: 30 KB per buffer + 20 KB; 4 measures the same)
 #endif
@@ -622,6 +625,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             }                                                                                            \
             d_ = __builtin_amdgcn_readfirstlane(d_ + lds_base + (buf) * (BUF_F4 * 16));                  \
             unsigned keep_;                                                                              \
+            if (MMLF_DMA_A_NT && (k) < nA)       /* A/B option: the once-read activation stream non-temporal */ \
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                   \
+                             "global_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"                    \
+                             : "=&s"(keep_) : "v"(vo_), "s"(sb_), "s"(d_) : "memory");                  \
+            else                                                                                         \
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                       \
                          "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"                           \
                          : "=&s"(keep_) : "v"(vo_), "s"(sb_), "s"(d_) : "memory");                      \
