@@ -81,7 +81,7 @@ class GradBuckets:
 class TrainStep:
     def __init__(self, model, lr, variant=None, warm_start=False, cooling=0, betas=(0.9, 0.999), eps=1e-8,
                  loss_margin=11, process_group=None, loss_multimodal=False, loss_padding=None,
-                 train_eval_mode=False, train_eval_mode_start=0):
+                 train_eval_mode=False, train_eval_mode_start=0, loss_strongest=False):
         self.model = model
         # --train_eval_mode / --train_eval_mode_start (train/cli.py:227-230): BatchNorm uses its running statistics
         self.eval_mode, self.eval_mode_start = bool(train_eval_mode), int(train_eval_mode_start)
@@ -90,6 +90,10 @@ class TrainStep:
         self.variant = variant or ('upr' if model.uncert else ('dpp' if model.discrete else 'base'))
         # --train_loss_multimodal: `gt` is the multi-plane tensor (B,P,5,H,W) (train/cli.py:120-123,201-225)
         self.multimodal, self.loss_padding = bool(loss_multimodal), loss_padding
+        # --train_loss_strongest (train/cli.py:190-192): `gt` is the multi-plane tensor too, and the target is the depth of
+        # the plane with the largest alpha; the CLI rejects it together with --train_loss_multimodal (train/cli.py:61)
+        self.strongest = bool(loss_strongest)
+        assert not (self.strongest and self.multimodal)
         self.flat, self.layout = flatten_parameters(model)
         self.grad = torch.zeros_like(self.flat)
         self.exp_avg = torch.zeros_like(self.flat)
@@ -127,6 +131,13 @@ class TrainStep:
             self._margin_mask[key] = loss_mod.create_mask_margin(mask.shape, self.margin).to(mask.device).int()
         return mask.int() * self._margin_mask[key]    # train/cli.py:194
 
+    @staticmethod
+    def strongest_gt(mpi):
+        """train/cli.py:190-192: per pixel the depth (plane 4) of the layer whose alpha (plane 3) is largest, first one on
+        ties (torch.max).  (B, P, 5, H, W) -> (B, H, W); the reference's bare ``.squeeze()`` also drops a batch axis of 1."""
+        inds = torch.max(mpi[:, :, 3, :, :], dim=1)[1].unsqueeze(1)
+        return torch.gather(mpi[:, :, 4, :, :], dim=1, index=inds).squeeze(1)
+
     def _den_override(self, mask):
         if not self.distributed:
             return None
@@ -143,6 +154,8 @@ class TrainStep:
         else:
             model.train()
         lr = self.current_lr(iteration)
+        if self.strongest:
+            gt = self.strongest_gt(gt).contiguous()
         mask = self._mask(mask)
         den = self._den_override(mask)
         self.grad.zero_()

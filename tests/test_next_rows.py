@@ -118,6 +118,37 @@ def test_multimodal_train_step(dev, variant):
         assert float((got - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-6, n
 
 
+@pytest.mark.parametrize('dev', DEVICES)
+@pytest.mark.parametrize('variant', ['base', 'dpp'])
+def test_strongest_depth_train_step(dev, variant):
+    """--train_loss_strongest (train/cli.py:190-192): the target is the depth of the plane with the largest alpha -- the
+    step on the multi-plane tensor equals the plain step on the gathered target, and the CLI's exclusion is kept."""
+    g = load_golden('g6_multimodal.npz')
+    kw = dict(TINY_KW, model_discrete=(variant == 'dpp'))
+    state = synth.synth_state(synth.param_spec(**kw), 9)
+
+    def fresh():
+        m = FeedForward(**kw)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        return m.to(dev)
+
+    stacks, _, _ = synth.synth_inputs(2, 14, seed=3, ps_w=18)
+    data = [torch.from_numpy(s).to(dev) for s in stacks]
+    mpi, mask = torch.from_numpy(g['mpi']).to(dev), torch.from_numpy(g['mask']).to(dev)
+    # the two lines of the reference loop, literally
+    inds = torch.max(mpi[:, :, 3, :, :], dim=1)[1].unsqueeze(1)
+    want_gt = torch.gather(mpi[:, :, 4, :, :], dim=1, index=inds).squeeze()
+    torch.testing.assert_close(TrainStep.strongest_gt(mpi), want_gt, rtol=0, atol=0)
+    assert float((want_gt - mpi[:, 0, 4]).abs().max()) > 0        # not simply the first plane
+    a = TrainStep(fresh(), lr=1e-3, loss_margin=2, loss_strongest=True)
+    b = TrainStep(fresh(), lr=1e-3, loss_margin=2)
+    la, lb = a(*data, mpi, mask, 1), b(*data, want_gt.contiguous(), mask, 1)
+    assert float(la) == float(lb)
+    assert torch.equal(a.grad, b.grad) and torch.equal(a.flat, b.flat)
+    with pytest.raises(AssertionError):
+        TrainStep(fresh(), lr=1e-3, loss_strongest=True, loss_multimodal=True)
+
+
 class _StubModel(torch.nn.Module):
     """returns fixed head outputs: pins the validation loop itself, not the network"""
 
