@@ -41,6 +41,51 @@ def flatten_parameters(model):
     return flat, layout
 
 
+LOG_HEADER = f'{"iter":>7}, loss_train,   loss_val,        mse, badpix_007, time_elapsed'      # train/cli.py:168
+
+
+def log_line(i, loss_train, loss_val_avg, mse_avg, bad_pix_avg, time_elap):
+    """one row of the reference's log.csv / stdout table (train/cli.py:327)"""
+    return (f'{i:>7}, {float(loss_train):.8f}, {float(loss_val_avg):.8f}, {float(mse_avg):.8f}, '
+            f'{float(bad_pix_avg):.8f}, {float(time_elap):.8f}')
+
+
+@torch.no_grad()
+def validation_pass(val_model, batches, uncert=False, loss_multimodal=False, margin=15, out_dir=None, scene_names=None):
+    """The periodic validation inside the training loop (reference train/cli.py:265-318, every --val_interval
+    iterations): eval mode; per validation batch the `margin`-px frame mask (--val_loss_margin), the forward pass of
+    `val_model` (the network, or its Ensamble under --val_ensamble), the TRAINING loss family on it -- the uncertainty
+    loss for --model_uncert, else the L1 loss (also for --model_discrete: the loop validates the DPP head's `mean` with
+    L1, :291-300), their multimodal forms on `mpi` under --train_loss_multimodal, never a padding mask -- plus masked MSE
+    and BadPix(0.07), and the result files (mean, logvar) in the dataset's save_batch layout.  `batches` yields the
+    loader's 9-tuples (h, v, i, d, center, gt, mpi, mask, index).  Returns (loss_val_avg, mse_avg, bad_pix_avg) as
+    floats: what ModelSaver (`loss=`) and the log row take (:320-327)."""
+    from . import results
+    if out_dir is not None and scene_names is None:
+        raise ValueError('validation_pass: out_dir needs scene_names (the dataset\'s scenes_names, indexed by `index`)')
+    val_model.eval()
+    loss_fn = loss_mod.MultiMaskedL1Loss() if loss_multimodal else loss_mod.MaskedL1Loss()
+    loss_uncert_fn = loss_mod.ImprovedMultiUncertaintyL1Loss() if loss_multimodal else loss_mod.ImprovedUncertaintyL1Loss()
+    mse_fn, bad_pix_fn = loss_mod.MaskedMSELoss(), loss_mod.MaskedBadPix()
+    loss_val_avg, mse_avg, bad_pix_avg, n = 0.0, 0.0, 0.0, 0
+    for data in batches:
+        h, v, i_, d, center, gt, mpi, _, index = data
+        mask = loss_mod.create_mask_margin(gt.shape, margin).to(gt.device)
+        output = val_model(h, v, i_, d)
+        target = mpi if loss_multimodal else gt
+        loss_val = (loss_uncert_fn if uncert else loss_fn)(output, target, mask)
+        loss_val_avg += float(loss_val)
+        mse_avg += float(mse_fn(output, gt, mask))
+        bad_pix_avg += float(bad_pix_fn(output, gt, mask))
+        if out_dir is not None:                  # valset.save_batch(output_dir, index, mean, logvar), :309-316
+            results.save_batch(out_dir, scene_names, index, gt=gt, result=output['mean'], uncert=output.get('logvar'),
+                               center=center, views=(h, v, i_, d))
+        n += 1
+    if n == 0:      # (the reference divides by j + 1 of an empty loop: NameError; an empty validation set is an error here too)
+        raise ValueError('validation_pass: no validation batches')
+    return loss_val_avg / n, mse_avg / n, bad_pix_avg / n
+
+
 class GradBuckets:
     """Contiguous slices of the flat gradient, one per out_net block / stream net, all-reduced as
     soon as the backward pass has finished the layers they cover."""

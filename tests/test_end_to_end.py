@@ -65,6 +65,15 @@ def test_train_checkpoint_resume_validate(variant, tmp_path):
             yield tuple(torch.from_numpy(np.asarray(a)).unsqueeze(0).cuda() for a in s[:8]) + (torch.tensor([[k]]),)
     rows, avg = validate.validate_scenes(model2, frames(), margin=4, out_dir=str(tmp_path), scene_names=['s0', 's1', 's2'])
     assert len(rows) == 3 and np.isfinite([v for r in rows for v in r.values()]).all()
+    # the training loop's own periodic validation (train/cli.py:265-325) on the same frames: same MSE / BadPix averages as
+    # the validate CLI's loop, the loss of the training family beside them, a checkpoint and a log row from its numbers
+    from mmlf_amd.train import log_line, validation_pass
+    lv, mse_v, bp_v = validation_pass(model2, frames(), uncert=(variant == 'upr'), margin=4, out_dir=str(tmp_path / 'val'),
+                                      scene_names=['s0', 's1', 's2'])
+    np.testing.assert_allclose([mse_v, bp_v], [avg['mse'], avg['badpix']], rtol=1e-6)
+    assert np.isfinite(lv) and (tmp_path / 'val' / 'ours' / 'disp_maps' / 's1.pfm').exists()
+    dl.ModelSaver()(str(tmp_path / 'val' / 'checkpoint.pt'), model2, step2, kw, None, 61, lv)
+    assert torch.load(str(tmp_path / 'val' / 'checkpoint.pt'))['loss'] == lv and log_line(61, cont2, lv, mse_v, bp_v, 0.1)
     res = pfm.load(str(tmp_path / 'ours' / 'disp_maps' / 's2.pfm'))
     assert res.shape == (72, 72) and res.dtype == np.float32
     # the trained model is better than predicting zero on the frames it saw patches of
