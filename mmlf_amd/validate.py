@@ -19,6 +19,32 @@ def validate_scene(model, h_views, v_views, i_views, d_views, gt, margin=15):
     return output, mse, badpix
 
 
+def model_from_checkpoint(path, model_discrete=False, val_disp_min=-3.5, val_disp_max=3.5, val_ensamble=False,
+                          val_disp_step=0.1, train_shift=0.0, device='cuda', map_location=None):
+    """validate/cli.py:213-241: the network is rebuilt from the checkpoint's own hyper-parameters, with the CLI's overrides
+    (`model_discrete`, the disparity range, `train_shift`), its weights loaded, wrapped in an Ensamble under --val_ensamble.
+    Returns (model, hyper-parameter dict, parameter count as the CLI prints it)."""
+    from .ensamble import Ensamble
+    from .feed_forward import FeedForward
+    state = torch.load(path, map_location=map_location or device)
+    kwargs = dict(state['hyper_parameters'])
+    kwargs.update({'model_discrete': model_discrete, 'val_disp_min': val_disp_min, 'val_disp_max': val_disp_max,
+                   'train_shift': train_shift})
+    model = FeedForward(**kwargs).to(device)
+    model.load_state_dict(state['model_state_dict'])
+    if val_ensamble:
+        model = Ensamble(model, val_disp_min, val_disp_max, val_disp_step)
+    return model, kwargs, sum(p.numel() for p in model.parameters())
+
+
+def table_rows(avg, runtime):
+    """the two LaTeX table lines the validate CLI prints at its end (validate/cli.py:350-351); `avg` as validate_scenes
+    returns it, `runtime` the LAST scene's (the CLI prints the loop variable)"""
+    return ('MSE & BadPix007 & KLD_UM & KLD_MM & KLD & - & TIME \\\\',
+            f"{avg['mse']:.3f} & {avg['badpix']:.3f} & {avg['kld_um']:.3f} & {avg['kld_mm']:.3f} & {avg['kld']:.3f} & - & "
+            f"{runtime:.3f} \\\\")
+
+
 @torch.no_grad()
 def validate_scenes(model, scenes, val_disp_min=-3.5, val_disp_max=3.5, margin=15, out_dir=None, scene_names=None,
                     n_bins=108, reference_compat=True):

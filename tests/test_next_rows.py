@@ -118,6 +118,27 @@ def test_multimodal_train_step(dev, variant):
         assert float((got - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-6, n
 
 
+def test_validate_cli_model_setup_and_table(tmp_path):
+    """validate/cli.py:213-247,350-351: the model comes from the checkpoint's own hyper-parameters plus the CLI's overrides --
+    here from the checkpoint the REFERENCE's ModelSaver wrote (tests/golden/g9_checkpoint.pt) -- and the closing table rows"""
+    import os
+    from mmlf_amd import validate
+    from mmlf_amd.ensamble import Ensamble
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'g9_checkpoint.pt')
+    ck = torch.load(path, map_location='cpu')
+    model, kw, n_params = validate.model_from_checkpoint(path, device='cpu')
+    assert isinstance(model, FeedForward) and kw['model_chs'] == ck['hyper_parameters']['model_chs']
+    assert kw['val_disp_min'] == -3.5 and kw['train_shift'] == 0.0 and kw['model_discrete'] is False
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, ck['model_state_dict'][k]), k
+    assert n_params == sum(v.numel() for k, v in ck['model_state_dict'].items() if 'running' not in k and 'num_batches' not in k)
+    ens, _, n2 = validate.model_from_checkpoint(path, val_ensamble=True, val_disp_step=0.5, device='cpu')
+    assert isinstance(ens, Ensamble) and len(ens.members()) == 14 and n2 == n_params
+    head, row = validate.table_rows({'mse': 1.23456, 'badpix': 2.0, 'kld_um': 0.1, 'kld_mm': 0.25, 'kld': 0.3}, 0.4444)
+    assert head == 'MSE & BadPix007 & KLD_UM & KLD_MM & KLD & - & TIME ' + 2 * chr(92)
+    assert row == '1.235 & 2.000 & 0.100 & 0.250 & 0.300 & - & 0.444 ' + 2 * chr(92)
+
+
 @pytest.mark.parametrize('kind', ['base', 'upr', 'dpp'])
 @pytest.mark.parametrize('multimodal', [False, True])
 def test_in_loop_validation_pass(kind, multimodal, tmp_path):
