@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build another copy of the library for A/B runs:  tools/build_variant.sh NAME [-DFLAG ...]
-# -> variants/lib_NAME.so (git-ignored, travels with gpurun); select it with MMLF_HIP_LIB=variants/lib_NAME.so
+# -> variants/lib_NAME.so (git-ignored AND gpurun-ignored: run this script on the GPU box, inside the gpurun command, in front of
+#    the A/B; hipcc is there and a build takes 25 s); select it with MMLF_HIP_LIB=variants/lib_NAME.so
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
