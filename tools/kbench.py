@@ -19,14 +19,22 @@ def amax_for(t, cs):
     return geo.amax_of(t, cs) if NEW else t.abs().max().reshape(1)
 
 
+STAMPS = []      # KBENCH_STAMP=1: wall-clock windows of every timed loop (tools/power_kernels.sh aligns rocm-smi samples with them)
+
+
 def timeit(fn):
+    if os.environ.get('KBENCH_STAMP'):          # progress on stderr: which loop a fault or a hang belongs to
+        print(f'kbench: loop {len(STAMPS)} starts', file=sys.stderr, flush=True)
     fn(); fn()
     torch.cuda.synchronize()
     ts = []
+    import time
+    t_begin = time.time()
     for _ in range(REPS):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
+    STAMPS.append((t_begin, time.time()))
     ts.sort()
     return ts[len(ts) // 2], ts[0]
 
@@ -71,8 +79,9 @@ def run(cin, cout):
     wsb = ws.wgrad_ws(geo, cin, cout) if NEW else ws.wgrad_ws(cin, cout)
     res['wgrad_p1'] = (timeit(lambda: engine.wgrad(geo, x, cs_in, cin, g1, cs_out, cout, 0, gw, gb, 0, wsb)), fl1)
     res['wgrad_p0'] = (timeit(lambda: engine.wgrad(geo, y, cs_out, cout, g0, cs_out, cout, geo.P + 1, gw, gb, 0, wsb)), fl0)
-    for k, ((med, mn), fl) in res.items():
-        print(f'{TAG} {cin}->{cout} B={B} {k:14s} median {med:8.3f} ms  min {mn:8.3f} ms  {fl / med / 1e9:7.1f} TFLOP/s', flush=True)
+    for (k, ((med, mn), fl)), (t0, t1) in zip(res.items(), STAMPS[-len(res):]):
+        stamp = f'  window {t0:.3f} {t1:.3f}' if os.environ.get('KBENCH_STAMP') else ''
+        print(f'{TAG} {cin}->{cout} B={B} {k:14s} median {med:8.3f} ms  min {mn:8.3f} ms  {fl / med / 1e9:7.1f} TFLOP/s{stamp}', flush=True)
 
 
 def run_wgrad(cin, cout):

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Socket power per launch kind: tools/kbench.py with long timed loops (KBENCH_STAMP=1 prints each loop's wall-clock window), rocm-smi
+# sampled beside it, samples averaged per window.   gpurun -- bash tools/power_kernels.sh gpurun_out/power_kernels.log [reps]
+out=${1:-gpurun_out/power_kernels.log}
+reps=${2:-250}
+mkdir -p "$(dirname "$out")"
+KBENCH_STAMP=1 python tools/kbench.py 512 $reps power > "$out.kbench" 2> "$out.err" &
+pid=$!
+: > "$out.smi"
+while kill -0 $pid 2>/dev/null; do
+  { date +%s.%N; rocm-smi --showpower --showclocks 2>/dev/null | grep -E 'Power|sclk'; } >> "$out.smi"
+  sleep 0.15
+done
+wait $pid
+python3 - "$out" <<'PY'
+import re, sys
+out = sys.argv[1]
+samples = []
+for b in re.split(r'\n(?=\d{10}\.\d+)', open(out + '.smi').read()):
+    m = re.match(r'(\d+\.\d+)', b); p = re.search(r'Power \(W\): ([\d.]+)', b); s = re.search(r'sclk clock level: \S+ \((\d+)Mhz\)', b)
+    if m and p and s:
+        samples.append((float(m.group(1)), float(p.group(1)), int(s.group(1))))
+with open(out, 'w') as f:
+    for line in open(out + '.kbench'):
+        m = re.search(r'window (\d+\.\d+) (\d+\.\d+)', line)
+        if not m:
+            continue
+        t0, t1 = float(m.group(1)), float(m.group(2))
+        inside = [s for s in samples if t0 + 0.3 <= s[0] <= t1 - 0.1]       # (rocm-smi's reading lags by a sample)
+        txt = line.split('  window')[0].rstrip()
+        if inside:
+            txt += '   power %4.0f W (%4.0f-%4.0f, %d samples)  sclk %4.0f MHz' % (
+                sum(s[1] for s in inside) / len(inside), min(s[1] for s in inside), max(s[1] for s in inside), len(inside),
+                sum(s[2] for s in inside) / len(inside))
+        f.write(txt + '\n')
+print(open(out).read())
+PY
