@@ -41,8 +41,29 @@ const char *mmlf_last_error(void);
 /* Bumped whenever an entry point's arguments or a layout they share changes.  mmlf_abi_version() returns the value the
  * library was BUILT with: a binding compares it with the header it was written against (mmlf_amd/_lib.py does, and reads
  * the number from this line) before making any other call. */
-#define MMLF_ABI_VERSION 6
+#define MMLF_ABI_VERSION 7
 int mmlf_abi_version(void);
+
+/* What the binary is: one line with the ABI version, the source revision it was built from and the value of every build
+ * switch that changes behaviour ("abi=7 git=... MMLF_ABL_TERMS=3 ... ablation=0").  mmlf_build_is_ablation() is nonzero for a
+ * build that computes WRONG results by construction (the timing ablations of csrc/conv.hip): a binding must refuse such a
+ * library unless its user asked for it (mmlf_amd/_lib.py: MMLF_ALLOW_ABLATION=1). */
+const char *mmlf_build_info(void);
+int mmlf_build_is_ablation(void);
+/* compute units the persistent conv / weight-gradient launches size their grids by: the device's count, or the cap the
+ * environment variable MMLF_CONV_CUS sets (leaves CUs free for a collective's kernels under data parallelism) */
+int mmlf_conv_cus(void);
+
+/* Bounds audit: END (largest byte offset + 1) of what ONE launch of mmlf_conv2x2_h2 / mmlf_conv2x2_wgrad_h2 of the given
+ * shape may touch behind each of its pointer arguments, derived from the launch geometry (csrc/conv.hip, end of file).
+ * A caller that allocates what the size queries below say is inside every end: tests/test_bounds_audit.py asserts it. */
+enum { MMLF_AUDIT_IN = 0, MMLF_AUDIT_PACKED = 1, MMLF_AUDIT_BIAS = 2, MMLF_AUDIT_OUT = 3, MMLF_AUDIT_REF = 4,
+       MMLF_AUDIT_IN_AMAX = 5, MMLF_AUDIT_OUT_AMAX = 6, MMLF_AUDIT_BN_PARTIAL = 7, MMLF_AUDIT_MASK = 8, MMLF_AUDIT_CONV_N = 9 };
+int mmlf_audit_conv_h2(int cs_in, int K, int N, int cs_out, int N_store, int out_shift, int cs_ref, int B, int H, int W,
+                       int64_t *ends);
+enum { MMLF_AUDIT_WG_IN = 0, MMLF_AUDIT_WG_G = 1, MMLF_AUDIT_WG_GW = 2, MMLF_AUDIT_WG_GB = 3, MMLF_AUDIT_WG_WORKSPACE = 4,
+       MMLF_AUDIT_WG_IN_AMAX = 5, MMLF_AUDIT_WG_G_AMAX = 6, MMLF_AUDIT_WGRAD_N = 7 };
+int mmlf_audit_wgrad_h2(int cs_in, int Cin, int cs_g, int Cout, int g_shift, int B, int H, int W, int64_t *ends);
 
 /* number of positions a grid buffer must provide for batch B and image extent H x W */
 int64_t mmlf_grid_alloc_positions(int B, int H, int W);

@@ -19,6 +19,11 @@ _d = ctypes.c_double
 SIGNATURES = {
     'mmlf_last_error': (ctypes.c_char_p, []),
     'mmlf_abi_version': (_i, []),
+    'mmlf_build_info': (ctypes.c_char_p, []),
+    'mmlf_build_is_ablation': (_i, []),
+    'mmlf_conv_cus': (_i, []),
+    'mmlf_audit_conv_h2': (_i, [_i] * 10 + [_vp]),
+    'mmlf_audit_wgrad_h2': (_i, [_i] * 8 + [_vp]),
     'mmlf_grid_alloc_positions': (_i64, [_i, _i, _i]),
     'mmlf_packed_filter_floats': (_i64, [_i, _i]),
     'mmlf_wgrad_workspace_floats': (_i64, [_i, _i, _i, _i, _i]),
@@ -84,28 +89,54 @@ def _header_abi_version():
 
 ABI_VERSION = _header_abi_version()     # bumped whenever an entry point's arguments change
 _lib = None
+BUILD_INFO = None
+
+
+def validate(lib, path, environ=None):
+    """Refuse a library this package must not call: another ABI version (its entry points would be called with shifted
+    arguments) or a build that computes WRONG results by construction -- the timing ablations of csrc/conv.hip
+    (`mmlf_build_is_ablation()`), unless MMLF_ALLOW_ABLATION=1 says the user wants exactly that (kernel A/B runs).
+    `lib` is anything with the three entry points (the tests pass a stub).  Returns the build string."""
+    environ = os.environ if environ is None else environ
+    got = lib.mmlf_abi_version() if hasattr(lib, 'mmlf_abi_version') else None
+    if got != ABI_VERSION:
+        raise RuntimeError(f'{path} implements ABI version {got}, this package needs {ABI_VERSION}: rebuild it '
+                           'with `python -m mmlf_amd.csrc.build --force`')
+    if not hasattr(lib, 'mmlf_build_info') or not hasattr(lib, 'mmlf_build_is_ablation'):
+        raise RuntimeError(f'{path} does not say what it was built with (no mmlf_build_info): rebuild it')
+    info = lib.mmlf_build_info()
+    info = info.decode() if isinstance(info, bytes) else str(info)
+    if lib.mmlf_build_is_ablation() and environ.get('MMLF_ALLOW_ABLATION') != '1':
+        raise RuntimeError(f'{path} is a timing-ablation build that computes WRONG results ({info}); it is refused unless '
+                           'MMLF_ALLOW_ABLATION=1 is set (unset MMLF_HIP_LIB to use the product library)')
+    return info
 
 
 def load():
     """Load the shared library once; raise if it is absent (no fallback)."""
-    global _lib
+    global _lib, BUILD_INFO
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f'{LIB_PATH} not found: build it with `python -m mmlf_amd.csrc.build` '
                 '(the HIP path has no CPU fallback)')
         lib = ctypes.CDLL(LIB_PATH)
-        # a stale or A/B build that still exports the names would be called with shifted arguments: refuse it here
-        if not hasattr(lib, 'mmlf_abi_version') or lib.mmlf_abi_version() != ABI_VERSION:
-            got = lib.mmlf_abi_version() if hasattr(lib, 'mmlf_abi_version') else None
-            raise RuntimeError(f'{LIB_PATH} implements ABI version {got}, this package needs {ABI_VERSION}: rebuild it '
-                               'with `python -m mmlf_amd.csrc.build --force`')
+        for name in ('mmlf_abi_version', 'mmlf_build_info', 'mmlf_build_is_ablation'):
+            if hasattr(lib, name):
+                getattr(lib, name).restype, getattr(lib, name).argtypes = SIGNATURES[name]
+        BUILD_INFO = validate(lib, LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def build_info():
+    """the loaded library's mmlf_build_info() string (bench.py prints it in config.build)"""
+    load()
+    return BUILD_INFO
 
 
 def last_error():

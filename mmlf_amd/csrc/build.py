@@ -20,22 +20,38 @@ def stale():
     return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not stale():
+def source_revision():
+    """short git hash of the tree the library is built from ('+' if the kernel sources differ from it), for mmlf_build_info()"""
+    root = os.path.dirname(os.path.dirname(HERE))
+    try:
+        rev = subprocess.check_output(['git', '-C', root, 'rev-parse', '--short=12', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+        dirty = subprocess.call(['git', '-C', root, 'diff', '--quiet', 'HEAD', '--', 'mmlf_amd/csrc', 'include'],
+                                stderr=subprocess.DEVNULL) != 0
+        return rev + ('+' if dirty else '')
+    except (OSError, subprocess.CalledProcessError):
+        return 'unknown'          # (no git on the GPU box's snapshot: the library that travels there was built here)
+
+
+def build(force=False, verbose=True, extra_flags=(), lib=None):
+    """extra_flags / lib: another build of the same sources somewhere else (tests/test_gpu_bounds.py: -DMMLF_BOUNDS_DEBUG)"""
+    if lib is None and not extra_flags and not force and not stale():
         return LIB
+    lib = lib or LIB
+    tag = '' if lib == LIB else '.' + os.path.basename(lib).replace('.so', '')
+    flags = [*FLAGS, f'-DMMLF_GIT_HASH="{source_revision()}"', *extra_flags]
     objs = []
     for src in SOURCES:
-        obj = os.path.join(HERE, src.replace('.hip', '.o'))
-        cmd = [HIPCC, *FLAGS, '-c', os.path.join(HERE, src), '-o', obj]
+        obj = os.path.join(os.path.dirname(lib), src.replace('.hip', tag + '.o'))
+        cmd = [HIPCC, *flags, '-c', os.path.join(HERE, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB]
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
 
 #define MMLF_TILE 256  // positions per conv tile (== MMLF_TILE_POSITIONS)
 #define MMLF_TILE_MAX 512  // ... of the sixteen-wave variant of the narrow layers: grids are padded to this
@@ -38,16 +39,41 @@ static inline int current_device()
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
     return d;
 }
+// One-time set-up per device ordinal (hipFuncSetAttribute is per device; nn.DataParallel drives one thread per device and
+// nothing stops two of them from sharing a device).  run(f) executes f ONCE per device, every caller -- also one that
+// arrives while another thread is inside f -- returns only after f has finished, and f's status (0 = ok) is what every
+// later call returns too: a failed set-up fails every launch of that kernel loudly instead of faulting later.
+// (Until round 5 this was a flag set BEFORE the work: a second thread could launch a 151 KB-LDS kernel ahead of the
+// attribute that allows it.)
 struct PerDeviceOnce {
-    bool done[64] = {};
-    bool first()      // idempotent work only: a benign race repeats it
+    std::once_flag flag[64];
+    int status[64] = {};
+    template <class F> int run(F &&f)
     {
         const int d = current_device();
-        if (done[d]) return false;
-        done[d] = true;
-        return true;
+        std::call_once(flag[d], [&] { status[d] = f(); });
+        return status[d];
     }
 };
+// the usual work: allow `bytes` of dynamic LDS for `kernel` on the current device
+static inline int mmlf_allow_lds(const void *kernel, size_t bytes, const char *what)
+{
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        return mmlf_fail("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed: %s", what, bytes, hipGetErrorString(e));
+    return 0;
+}
+
+// -DMMLF_BOUNDS_DEBUG: the convolution / weight-gradient kernels COUNT every access that leaves what the ABI says their
+// buffers hold (slot = which argument; tests/test_gpu_bounds.py builds such a library on the GPU box, runs the launch kinds of
+// a training step and of tools/kbench.py through it and expects zeros).  Off in the product build: the macro is empty.
+#ifdef MMLF_BOUNDS_DEBUG
+extern __device__ unsigned long long g_mmlf_oob[8];
+#define MMLF_OOB(slot, cond) do { if (cond) atomicAdd(&g_mmlf_oob[slot], 1ull); } while (0)
+#else
+#define MMLF_OOB(slot, cond) do { } while (0)
+#endif
+enum { OOB_OUT = 0, OOB_IN = 1, OOB_WG_IN = 2, OOB_WG_G = 3, OOB_AMAX = 4, OOB_MASK = 5, OOB_WG_PART = 6, OOB_REF = 7 };
 
 // Padded-grid geometry of one launch (see include/mmlf_hip.h).
 // Columns / rows a patch's grid has beyond its image: 2 and 2, a zero column and row of its own on every side.  The flat

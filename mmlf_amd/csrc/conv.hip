@@ -16,6 +16,19 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef MMLF_BOUNDS_DEBUG
+__device__ unsigned long long g_mmlf_oob[8];
+extern "C" int mmlf_debug_oob_counts(unsigned long long *host8, int reset)
+{
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_mmlf_oob), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        const unsigned long long z[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_mmlf_oob), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // filter packing: OIHW master -> [chunk][tap][kh][NP][4] with k = 8*chunk + 4*kh + s
 // ---------------------------------------------------------------------------------------------
@@ -64,7 +77,20 @@ struct ConvArgs {
                                          // [block][2][n_true] doubles, the input of the BatchNorm finalize
     unsigned *relu_mask_out;             // optional: (out > 0) as bits, [tile][wave][8 rows][64 lanes] words, bit = column block
     const unsigned *relu_mask_in;        // optional: such a mask instead of relu_ref (same launch geometry and N)
+    // bytes the caller's buffers hold behind `out` / `ref` by the ABI's contract (mmlf_grid_alloc_positions): the epilogue's
+    // buffer descriptors carry what is left of them as num_records, so that a store or load past the allocation would be
+    // DROPPED by the address unit instead of faulting (round 5; until then the range check was switched off).  None is
+    // expected: tests/test_bounds_audit.py derives every launch's extents, and a -DMMLF_BOUNDS_DEBUG build counts them.
+    long long out_bytes, ref_bytes;
+    long long in_bytes, amax_n, mask_words;   // read by the MMLF_BOUNDS_DEBUG build only
 };
+
+// wave-uniform descriptor of what is left of a buffer of `total` bytes behind byte offset `off` (32-bit num_records)
+__device__ __forceinline__ int mmlf_records_left(long long total, long long off)
+{
+    const long long left = total - off;
+    return left <= 0 ? 0 : (left > 0x7fffffffll ? 0x7fffffff : (int)left);
+}
 
 // epilogue shared by the f32 and the split-bf16 kernels: D[row = position][col = channel]; a lane
 // holds column i of every N tile and rows (r&3)+8(r>>2)+4kh of its wave's 32 positions.
@@ -75,40 +101,20 @@ struct ConvArgs {
 //  * addressing: buffer instructions on a wave-uniform tile descriptor + 32-bit per-lane byte offsets
 //    (the column-block offset folds into the instruction's immediate);
 //  * bias and (data-gradient) ReLU-reference values are loaded in batches ahead of their use.
-#ifndef MMLF_PRIO_LEVELS
-#define MMLF_PRIO_LEVELS 0   // levels of the progress-inverse wave priority in the chunk loops (0 = off; at most 4)
-#endif
-// s_setprio takes an immediate: the level folds to a constant once the column-block loops are unrolled
-__device__ __forceinline__ void mmlf_set_prio(int level)
-{
-    if (level >= 3) __builtin_amdgcn_s_setprio(3);
-    else if (level == 2) __builtin_amdgcn_s_setprio(2);
-    else if (level == 1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
-}
+// Build switches.  Round 5 removed the timing-ablation switches of rounds 3-4 whose experiments are closed (their numbers
+// stay in EXPERIMENTS.md 4.7-4.8: half weight-fragment reads, double split, pre-split operand, 32x32x16 tiles, no early
+// barrier, non-temporal activation DMA, wave priorities, the narrow kernel's timeline; check out round 4's tree to rebuild
+// them).  What is left changes either nothing observable (MMLF_RING16, MMLF_WGRAD_EARLY: tuning constants) or the RESULT:
+//   MMLF_ABL_TERMS < 3 -- run only 2 or 1 of the f16 split's three cross terms (a timing ablation: WRONG results);
+//   MMLF_ABL_WGRAD_STAGE -- timing ablations of the wide weight gradient's staging (below: WRONG results).
+// mmlf_build_info() reports every one of them and the Python loader refuses a library with a result-changing switch
+// unless MMLF_ALLOW_ABLATION=1 is set (mmlf_amd/_lib.py).
 #ifndef MMLF_ABL_TERMS
 #define MMLF_ABL_TERMS 3     // cross terms of the f16 split that are evaluated (3 = the arithmetic; fewer: timing ablation)
 #endif
-// timing ablations that bracket a 64-position x 144-column wave layout before it is built (WRONG results):
-#ifndef MMLF_ABL_HALFB
-#define MMLF_ABL_HALFB 0       // 1: a wave reads the weight fragments of every second column block only (half the LDS reads)
-#endif
-#ifndef MMLF_ABL_DSPLIT
-#define MMLF_ABL_DSPLIT 0      // 1: the activation split is done twice per chunk (what two column halves per tile would cost)
-#endif
-#ifndef MMLF_ABL_PRESPLIT
-#define MMLF_ABL_PRESPLIT 0    // 1: the activation operand arrives ALREADY split -- per position and 8-channel octet 16 bytes of f16
-#endif                         // `hi` then 16 bytes of `lo`, scale 2^10 (tools/presplit_bench.py makes such a tensor): what the wide
-                               // launches would take with producer-side splitting; results are correct for such input
-#ifndef MMLF_ABL_MFMA32
-#define MMLF_ABL_MFMA32 0      // 1: timing ablation of the 280-wide f16 kernel on v_mfma_f32_32x32x16_f16 -- the same fragment reads,
-#endif                         // registers and matrix-pipe cycles in half the MFMA instructions (operands not re-laid-out: WRONG results)
-#ifndef MMLF_ABL_NOEARLY
-#define MMLF_ABL_NOEARLY 0     // 1: no early barrier / next-chunk fragment prefetch (the registers a 4-row-block wave cannot spare)
-#endif
-#ifndef MMLF_DMA_A_NT
-#define MMLF_DMA_A_NT 0        // 1: the split-precision conv kernels fetch their ACTIVATION pieces with the non-temporal policy (A/B)
-#endif
+#ifndef MMLF_ABL_WGRAD_STAGE
+#define MMLF_ABL_WGRAD_STAGE 0   // wide weight gradient, timing ablations of its staging (WRONG results): 1 = the gradient tile
+#endif                           // is stored unsplit (no vector work on it); 2 = it is not staged at all after the first chunk
 #ifndef MMLF_RING16
 #define MMLF_RING16 3   // pipeline depth of the sixteen-wave conv variant (LDS: 30 KB per buffer + 20 KB; 4 measures the same)
 #endif
@@ -128,11 +134,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&
 {
     const unsigned m = wave_row_mask(a, Q0, w, i) >> (4 * kh);
     const long long qb = Q0 + 32 * w + a.out_shift;                                     // wave-uniform
-    const __amdgpu_buffer_rsrc_t ob =
-        __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)qb * a.cs_out, 0, 0x7fffffff, MMLF_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t ob = __builtin_amdgcn_make_buffer_rsrc(
+        a.out + (size_t)qb * a.cs_out, 0, mmlf_records_left(a.out_bytes, qb * a.cs_out * 4ll), MMLF_BUF_FLAGS);
     const bool has_ref = a.ref != nullptr;
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(has_ref ? a.ref + (size_t)qb * a.cs_ref : a.out), 0, 0x7fffffff, MMLF_BUF_FLAGS);
+        const_cast<float *>(has_ref ? a.ref + (size_t)qb * a.cs_ref : a.out), 0,
+        has_ref ? mmlf_records_left(a.ref_bytes, qb * a.cs_ref * 4ll) : 0, MMLF_BUF_FLAGS);
     unsigned lo = ((unsigned)(4 * kh) * a.cs_out + i) * 4u;
     unsigned lr = ((unsigned)(4 * kh) * a.cs_ref + i) * 4u;
     // the per-row offsets derived from these are tile-invariant: opaque to the optimiser so that it does
@@ -369,11 +376,13 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
     const bool mask_out = GEN ? a.relu_mask_out != nullptr : (EPI & EPI_MASK_OUT) != 0;
     const unsigned m = wave_row_mask(a, Q0, w, r16 + 16 * q4) >> (4 * q4);
     const long long qb = Q0 + 32 * w + a.out_shift;                                     // wave-uniform
+    const int ob_left = mmlf_records_left(a.out_bytes, qb * a.cs_out * 4ll);
     const __amdgpu_buffer_rsrc_t ob =
-        __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)qb * a.cs_out, 0, 0x7fffffff, MMLF_BUF_FLAGS);
+        __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)qb * a.cs_out, 0, ob_left, MMLF_BUF_FLAGS);
     const bool has_ref = GEN ? a.ref != nullptr : (EPI & EPI_REF_IN) != 0;
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(has_ref ? a.ref + (size_t)qb * a.cs_ref : a.out), 0, 0x7fffffff, MMLF_BUF_FLAGS);
+        const_cast<float *>(has_ref ? a.ref + (size_t)qb * a.cs_ref : a.out), 0,
+        has_ref ? mmlf_records_left(a.ref_bytes, qb * a.cs_ref * 4ll) : 0, MMLF_BUF_FLAGS);
     unsigned lo = ((unsigned)(4 * q4) * a.cs_out + r16) * 4u;
     unsigned lr = ((unsigned)(4 * q4) * a.cs_ref + r16) * 4u;
     asm volatile("" : "+v"(lo), "+v"(lr));   // see conv_epilogue
@@ -389,6 +398,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
     unsigned mw[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) mw[k] = use_bits ? a.relu_mask_in[mbase + 64 * k] : 0u;
+    MMLF_OOB(OOB_MASK, (use_bits || mask_out) && (long long)mbase + 64 * 7 >= a.mask_words);
     // bias and weight-unscale of all of this lane's columns up front: a load between the stores makes the compiler
     // wait for the wave's vector-memory counter to reach zero there, i.e. for every store issued so far (and every DMA
     // piece in flight) -- once per column block
@@ -417,8 +427,11 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
             float rv[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
+            {
+                MMLF_OOB(OOB_REF, (qb * a.cs_ref * 4ll) + lr + (long long)(16 * (k >> 2) + (k & 3)) * a.cs_ref * 4 + 64 * nb >= a.ref_bytes);
                 rv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                     rb, lr + (unsigned)(16 * (k >> 2) + (k & 3)) * a.cs_ref * 4u + 64 * nb, 0, 0));
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (!(rv[k] > 0.f)) keep &= ~(1u << (16 * (k >> 2) + (k & 3)));
@@ -434,6 +447,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
             s1 += v;
             s2 = fmaf(v, v, s2);
             // row offset in the scalar offset operand, column block in the immediate: no address arithmetic per element
+            MMLF_OOB(OOB_OUT, (long long)lo + 64 * nb + (long long)rc * a.cs_out * 4 >= ob_left);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ob, lo + 64 * nb, (unsigned)rc * a.cs_out * 4u, 0);
         }
         if (stats) {            // BatchNorm statistics: this wave's 32 positions of channel 16*nb + r16
@@ -449,7 +463,6 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
 #pragma unroll
         for (int k = 0; k < 8; ++k) a.relu_mask_out[mbase + 64 * k] = mw[k];
     }
-#ifndef MMLF_ABL_NO_CONV_AMAX      // timing ablation (tools/build_variant.sh): no row maxima from the conv epilogue
     if (a.out_amax) {
         const unsigned d0 = (unsigned)qb;                       // first destination position of the wave
         const unsigned rd0 = fastdiv(d0, a.divP);
@@ -464,6 +477,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
         m_lo = mmlf_wave_max(m_lo);
         m_hi = mmlf_wave_max(m_hi);
         if (r16 + 16 * q4 == 0) {
+            MMLF_OOB(OOB_AMAX, MMLF_AMAX_HEAD + (long long)fastdiv(d0 + 31, a.divP) >= a.amax_n);
             if (m_lo > 0.f) mmlf_amax_raise_nowait(a.out_amax + MMLF_AMAX_HEAD + rd0, m_lo);
             if (m_hi > 0.f) {
                 const unsigned rdl = fastdiv(d0 + 31, a.divP);
@@ -472,7 +486,6 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
             run_max = fmaxf(run_max, fmaxf(m_lo, m_hi));        // lane 0 carries the tensor maximum
         }
     }
-#endif
 }
 
 // f16 split: the power-of-two scale wave w of tile Q0 applies to its activation operand.  The wave's valid
@@ -490,6 +503,7 @@ __device__ __forceinline__ float wave_operand_amax_gather(const ConvArgs &a, lon
         const unsigned r0 = fastdiv((unsigned)q0, a.divP);
         unsigned r1 = fastdiv((unsigned)ql, a.divP);
         r1 += (r1 - fastdiv(r1, a.divR) * (unsigned)a.R != (unsigned)(a.R - 1)) ? 1u : 0u;
+        MMLF_OOB(OOB_AMAX, lane == 0 && MMLF_AMAX_HEAD + (long long)r1 >= a.amax_n);
         for (unsigned r = r0 + lane; r <= r1; r += 64) m = fmaxf(m, a.in_amax[MMLF_AMAX_HEAD + r]);
     }
     return m;
@@ -547,7 +561,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     // its last twelve MFMAs while they arrive -- the LDS latency of the chunk head (both waves of a SIMD stand in it at
     // once: 12 % of a 280-wide chunk by the wave's own clock) is off the critical path.  Needs G % 3 == 0 (the rotating
     // fragment slots line up across chunks) and enough column blocks behind the DMA issue for the pieces to land.
-    constexpr bool EARLY = !MMLF_ABL_NOEARLY && PL == 2 && G % 3 == 0 && G >= 9;   // (the three-plane build has no registers to spare for it)
+    constexpr bool EARLY = PL == 2 && G % 3 == 0 && G >= 9;   // (the three-plane build has no registers to spare for it)
     // A: [640 slots][channel half(2)] float4.  Slot s holds position Q0 + s (+ seg_delta for s >= 320).
     // When the pitch is small (P + 257 <= 640, e.g. 96x96 training patches) ONE contiguous window
     // Q0 .. Q0+256+P serves all four taps (taps 2,3 read at slot offset P): 355 positions per tile
@@ -606,6 +620,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     const unsigned tail_lim = ((unsigned)(a.a_tail - 1) * (unsigned)a.cs_in + 4u) * 4u;
     const unsigned b_src0 = 1024u * jb0, b_dst0 = (unsigned)(A_F4 + 64 * jb0) * 16u;
 
+#ifdef MMLF_BOUNDS_DEBUG      // the piece's last source byte against the buffer (the address is made scalar again for the asm)
+#define MMLF_DMA_SRC_CHECK()                                                                             \
+    do {                                                                                                 \
+        MMLF_OOB(OOB_IN, (long long)(sb_ - in0) + vo_ + 16 > a.in_bytes);                                \
+        const unsigned long long u_ = (unsigned long long)sb_;                                           \
+        sb_ = reinterpret_cast<const char *>(                                                            \
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(u_ >> 32)) << 32) |           \
+            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)u_));                                     \
+    } while (0)
+#else
+#define MMLF_DMA_SRC_CHECK() do { } while (0)
+#endif
     // slot 0 = this wave's pieces k < PER_SLOT, slot 1 = the rest; k is a compile-time index
 #define X6_DMA_PIECE(tl, c, buf, k)                                                                      \
     do {                                                                                                 \
@@ -617,6 +643,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                 d_ = a_dst[(k) < 3 ? (k) : 0];                                                           \
                 vo_ = min(voff_a, (d_ & 1u) ? tail_lim : 0xffffffffu);                                   \
                 d_ &= ~1u;                                                                               \
+                MMLF_DMA_SRC_CHECK();                                                                    \
             } else {                                                                                     \
                 const unsigned kb_ = (1024u * NW) * (unsigned)((k) - nA);                                \
                 sb_ = wp_base + (size_t)(c) * (B_F4 * 16) + b_src0 + kb_;                                \
@@ -625,11 +652,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             }                                                                                            \
             d_ = __builtin_amdgcn_readfirstlane(d_ + lds_base + (buf) * (BUF_F4 * 16));                  \
             unsigned keep_;                                                                              \
-            if (MMLF_DMA_A_NT && (k) < nA)       /* A/B option: the once-read activation stream non-temporal */ \
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                   \
-                             "global_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"                    \
-                             : "=&s"(keep_) : "v"(vo_), "s"(sb_), "s"(d_) : "memory");                  \
-            else                                                                                         \
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"                       \
                          "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"                           \
                          : "=&s"(keep_) : "v"(vo_), "s"(sb_), "s"(d_) : "memory");                      \
@@ -673,7 +695,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     float scale_a = 1.f, unscale_a = 1.f, run_max = 0.f;
     if constexpr (PL == 2) {
         scale_a = wave_operand_scale(wave_operand_amax_gather(late_args(), (long long)tile * TILE, w, lane));
-        if (MMLF_ABL_PRESPLIT && G == 18) scale_a = 1024.f;
         unscale_a = 1.f / scale_a;
     }
 #pragma unroll
@@ -738,11 +759,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                 split3_pair(ra[mb][1].z, ra[mb][1].w, hh[3], mm[3], ll[3]);
                 const u32x4_t vm = {mm[0], mm[1], mm[2], mm[3]};
                 asp[mb][1] = __builtin_bit_cast(bf16x8, vm);
-            } else if constexpr (MMLF_ABL_PRESPLIT && G == 18) {
-                hh[0] = __float_as_uint(ra[mb][0].x); hh[1] = __float_as_uint(ra[mb][0].y);
-                hh[2] = __float_as_uint(ra[mb][0].z); hh[3] = __float_as_uint(ra[mb][0].w);
-                ll[0] = __float_as_uint(ra[mb][1].x); ll[1] = __float_as_uint(ra[mb][1].y);
-                ll[2] = __float_as_uint(ra[mb][1].z); ll[3] = __float_as_uint(ra[mb][1].w);
             } else {
                 split2_pair_f16(ra[mb][0].x, ra[mb][0].y, scale_a, hh[0], ll[0]);
                 split2_pair_f16(ra[mb][0].z, ra[mb][0].w, scale_a, hh[1], ll[1]);
@@ -752,28 +768,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {ll[0], ll[1], ll[2], ll[3]};
             asp[mb][0] = __builtin_bit_cast(bf16x8, vh);
             asp[mb][PL - 1] = __builtin_bit_cast(bf16x8, vl);
-            if constexpr (MMLF_ABL_DSPLIT && PL == 2 && G == 18) {     // the same work once more, results discarded
-                float4 r0 = ra[mb][0], r1 = ra[mb][1];
-                asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
-                unsigned h2[4], l2[4];
-                split2_pair_f16(r0.x, r0.y, scale_a, h2[0], l2[0]);
-                split2_pair_f16(r0.z, r0.w, scale_a, h2[1], l2[1]);
-                split2_pair_f16(r1.x, r1.y, scale_a, h2[2], l2[2]);
-                split2_pair_f16(r1.z, r1.w, scale_a, h2[3], l2[3]);
-                asm volatile("" ::"v"(h2[0]), "v"(h2[1]), "v"(h2[2]), "v"(h2[3]), "v"(l2[0]), "v"(l2[1]), "v"(l2[2]), "v"(l2[3]));
-            }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-#if MMLF_PRIO_LEVELS > 1
-            // Progress-inverse wave priority.  The two waves of a SIMD share its matrix pipe, and the arbiter serves the
-            // older one first: it runs through its column blocks at full speed, waits at the chunk's barrier, and its
-            // partner finishes alone, at the 50 % matrix-pipe density of a single wave's instruction stream (the
-            // wave's own clock: 3 300 + 1 480 cycles against 4 680 + 110).  A wave that is further into its chunk
-            // lowers its priority, so whichever wave is behind is served first and the pair reaches the barrier together.
-            if (G >= 8 && (g == 0 || (g * MMLF_PRIO_LEVELS) / G != ((g - 1) * MMLF_PRIO_LEVELS) / G))
-                mmlf_set_prio(MMLF_PRIO_LEVELS - 1 - (g * MMLF_PRIO_LEVELS) / G);
-#endif
             if (EARLY && g == G - 2) {
                 // every LDS read of this chunk has been requested (weights run two column blocks ahead): wait for them and
                 // for the next chunk's DMA pieces, pass the barrier, then ask for the next chunk's activations
@@ -788,10 +785,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                 }
             }
             if (g + 2 < G) {
-                if (!(MMLF_ABL_HALFB && G == 18 && (g & 1))) {
 #pragma unroll
-                    for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bp[pl * 4 * NP + 16 * (g + 2)];
-                }
+                for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bp[pl * 4 * NP + 16 * (g + 2)];
             } else if (EARLY && !tile_end) {   // behind the barrier: the next chunk's first two column blocks (G % 3 == 0)
 #pragma unroll
                 for (int pl = 0; pl < PL; ++pl) bq[(g + 2) % 3][pl] = bpn[pl * 4 * NP + 16 * (g + 2 - G)];
@@ -813,7 +808,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
 #define H2_TERM(pa, pb)                                                                                      \
     _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
         acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),          \
-                                                            __builtin_bit_cast(f16x8, bq[(MMLF_ABL_HALFB && G == 18 && (g & 1) && g + 1 < G ? g + 1 : g) % 3][pb]), acc[mb][g], 0, 0, 0)
+                                                            __builtin_bit_cast(f16x8, bq[g % 3][pb]), acc[mb][g], 0, 0, 0)
             if constexpr (PL == 3) {
                 X6_TERM(2, 0);
                 X6_TERM(0, 2);
@@ -821,24 +816,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
                 X6_TERM(1, 0);
                 X6_TERM(0, 1);
                 X6_TERM(0, 0);
-            } else if constexpr (MMLF_ABL_MFMA32 && G == 18) {
-                // every second column block: six 32x32x16 instructions on a 16-register accumulator made of this and the
-                // next column block's tiles, fed with the fragments at hand (row blocks as the two K halves)
-                if ((g & 1) == 0) {
-                    f32x16 t;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { t[r] = acc[0][g][r]; t[4 + r] = acc[1][g][r]; t[8 + r] = acc[0][g + 1][r]; t[12 + r] = acc[1][g + 1][r]; }
-#define H32_TERM(pa, pb)                                                                                     \
-    _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
-        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),                   \
-                                                   __builtin_bit_cast(f16x8, bq[(g + mb) % 3][pb]), t, 0, 0, 0)
-                    H32_TERM(1, 0);
-                    H32_TERM(0, 1);
-                    H32_TERM(0, 0);
-#undef H32_TERM
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { acc[0][g][r] = t[r]; acc[1][g][r] = t[4 + r]; acc[0][g + 1][r] = t[8 + r]; acc[1][g + 1][r] = t[12 + r]; }
-                }
             } else {
                 // MMLF_ABL_TERMS (ablation builds only, WRONG results): run 2 or 1 of the three cross terms with everything
                 // else unchanged -- the time a launch would take with fewer matrix instructions per product
@@ -873,7 +850,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             if constexpr (PL == 2) {
                 if (tile < ntiles) {
                     scale_a = wave_operand_scale(next_amax);
-                    if (MMLF_ABL_PRESPLIT && G == 18) scale_a = 1024.f;
                     unscale_a = 1.f / scale_a;
                 }
             }
@@ -904,6 +880,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         }
     }
 #undef X6_DMA_PIECE
+#undef MMLF_DMA_SRC_CHECK
 #undef X6_DMA_SLOT
 #undef X6_DMA_WAIT
 #undef X6_CHUNK_WAIT
@@ -927,16 +904,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
 // Layouts (mask words, statistics, amax, scales) are indexed by the global 32-position group exactly as in
 // conv4tap_x6s_kernel (tile = group / 8, wave = group % 8): the two kernels write the same bytes.
 // ---------------------------------------------------------------------------------------------
-#ifdef MMLF_RS_TIMELINE      // diagnostic build (tools/rs_timeline.py): cycles per phase of a group by the wave's own clock
-__device__ unsigned long long g_rs_timeline[5 * 4096];
-extern "C" int mmlf_debug_rs_timeline(unsigned long long *host, int n)
-{
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rs_timeline), sizeof(unsigned long long) * (size_t)n);
-}
-#define RS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tl[i] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define RS_STAMP(i) do { } while (0)
-#endif
 template <int G, int NCH, int EPI>
 __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngroups)
 {
@@ -995,9 +962,6 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
     const size_t row_off = (size_t)r16 * a.cs_in;                                     // floats
     const size_t rem_off = (size_t)((q4 & 1) + (q4 >> 1) * a.P) * a.cs_in + 32 * NS;
 
-#ifdef MMLF_RS_TIMELINE
-    unsigned long long tl[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
     for (; gi < gend; gi += gstep) {
         const long long Q0 = (long long)(gi >> 3) * MMLF_TILE;
         const int wv = gi & 7;
@@ -1013,10 +977,12 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
+                {
+                    MMLF_OOB(OOB_IN, (long long)((pk + (size_t)(16 * mb) * a.cs_in + 4 * hf + 4) - a.in) * 4 > a.in_bytes);
                     raw[k][mb][hf] = reinterpret_cast<const float4 *>(pk + (size_t)(16 * mb) * a.cs_in)[hf];
+                }
             __builtin_amdgcn_sched_barrier(0);          // step order: the counted waits below rely on it
         }
-        RS_STAMP(0);                                     // issuing the loads
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD > 63 ? 63 : NLOAD) : "memory");
         const float scale_a = wave_operand_scale(gathered);
         const float unscale_a = 1.f / scale_a;
@@ -1029,22 +995,16 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
         for (int k = 0; k < NSTEP; ++k) {
             // loads come back in order: step k's four are done once at most 4 (NSTEP - 1 - k) younger ones are outstanding
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NSTEP - 1 - k) > 63 ? 63 : 4 * (NSTEP - 1 - k)) : "memory");
-            if (k == 0) RS_STAMP(1);                     // scale + wait for the first step's data (and older stores)
             bf16x8 asp[2][2];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 unsigned hh[4], ll[4];
                 float4 &r0 = raw[k][mb][0], &r1 = raw[k][mb][1];
                 asm volatile("" : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w));
-                if constexpr (MMLF_ABL_PRESPLIT) {     // timing ablation: the operand taken as already split (wrong results on float32 input)
-                    hh[0] = __float_as_uint(r0.x); hh[1] = __float_as_uint(r0.y); hh[2] = __float_as_uint(r0.z); hh[3] = __float_as_uint(r0.w);
-                    ll[0] = __float_as_uint(r1.x); ll[1] = __float_as_uint(r1.y); ll[2] = __float_as_uint(r1.z); ll[3] = __float_as_uint(r1.w);
-                } else {
-                    split2_pair_f16(r0.x, r0.y, scale_a, hh[0], ll[0]);
-                    split2_pair_f16(r0.z, r0.w, scale_a, hh[1], ll[1]);
-                    split2_pair_f16(r1.x, r1.y, scale_a, hh[2], ll[2]);
-                    split2_pair_f16(r1.z, r1.w, scale_a, hh[3], ll[3]);
-                }
+                split2_pair_f16(r0.x, r0.y, scale_a, hh[0], ll[0]);
+                split2_pair_f16(r0.z, r0.w, scale_a, hh[1], ll[1]);
+                split2_pair_f16(r1.x, r1.y, scale_a, hh[2], ll[2]);
+                split2_pair_f16(r1.z, r1.w, scale_a, hh[3], ll[3]);
                 const u32x4_t vh = {hh[0], hh[1], hh[2], hh[3]}, vl = {ll[0], ll[1], ll[2], ll[3]};
                 asp[mb][0] = __builtin_bit_cast(bf16x8, vh);
                 asp[mb][1] = __builtin_bit_cast(bf16x8, vl);
@@ -1074,28 +1034,17 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
 #undef RS_TERM
             }
         }
-        RS_STAMP(2);                                     // the steps: waits for later data, split, MFMAs
         // (round 4 also measured this epilogue with ROW stores -- values through a wave-private LDS image, 16-byte stores of
         // consecutive addresses, 1 KB per wave instruction instead of 64-byte segments: 0.96-1.0 ms either way, removed)
         conv_epilogue16<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max,
                                 a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
-        RS_STAMP(3);                                     // epilogue (the issue of its stores)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int nb = 0; nb < G; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
-#ifdef MMLF_RS_TIMELINE
-        tl[4] += 1;
-#endif
     }
-#ifdef MMLF_RS_TIMELINE
-    if (lane == 0) {
-        const int slot = ((int)blockIdx.x * 8 + w) & 4095;
-        for (int i = 0; i < 5; ++i) g_rs_timeline[5 * slot + i] = tl[i];
-    }
-#endif
     if (a.out_amax) mmlf_amax_update(run_max, a.out_amax, blockIdx.x * 8 + w);      // one atomic per wave per launch
     if (a.bn_partial) {
         __syncthreads();                                        // orders the waves' sums
@@ -1255,6 +1204,7 @@ struct WgradArgs {
     int cs_in, cin, cs_g, g_shift, P, nsplit, nslice, chunks_per_split, nchunks;
     const float *in_amax, *g_amax;   // f16 split: amax arrays of in and g (common.h)
     const float *chunk_scales;       // f16 split: [nchunks][2] power-of-two operand scales (wgrad_chunk_scales_kernel)
+    long long in_bytes, g_bytes, part_floats;   // what the buffers hold by contract: read by the MMLF_BOUNDS_DEBUG build only
 };
 
 // Block -> (slice, position split).  Blocks b, b + 8, ... land on one XCD (round-robin dispatch): the slices of one split are
@@ -1580,6 +1530,7 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
             const int seg = row >= 33, pix = row - 33 * seg;                                                \
             const int ch = ci0 + 4 * f;                                                                     \
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+            MMLF_OOB(OOB_WG_IN, idx < 66 * FA && ch < a.cs_in && ((Qc + seg * a.P + pix) * a.cs_in + ch + 4) * 4ll > a.in_bytes); \
             if (idx < 66 * FA && ch < a.cs_in)                                                              \
                 v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
             ra[j] = v;                                                                                      \
@@ -1588,6 +1539,7 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
             const int idx = tid + 256 * j;                                                                  \
             const int row = idx / FG, f = idx - row * FG;                                                   \
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
+            MMLF_OOB(OOB_WG_G, idx < WG_KQ * FG && 4 * f < a.cs_g && ((Qc + a.g_shift + row) * a.cs_g + 4 * f + 4) * 4ll > a.g_bytes); \
             if (idx < WG_KQ * FG && 4 * f < a.cs_g)                                                         \
                 v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + 4 * f); \
             rg[j] = v;                                                                                      \
@@ -1681,6 +1633,7 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mb + 4 * q4 + r;      // the ones row (bias gradient) carries no input scale
                 const float un = (ci0 + row == a.cin ? 1.f : sc.inv_sa) * sc.inv_sg;
+                MMLF_OOB(OOB_WG_PART, (long long)(pp - a.part) + (long long)row * NP + 16 * nb + r16 >= a.part_floats);
                 pp[(size_t)row * NP + 16 * nb + r16] = acc[mb][nb][r] * un;
             }
 }
@@ -1741,6 +1694,7 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         const int row = idx / FA, f = idx - row * FA;                                                       \
         const int seg = row >= 33, pix = row - 33 * seg;                                                    \
         const int ch = min(ci0 + 4 * f, a.cs_in - 4);                                                       \
+        MMLF_OOB(OOB_WG_IN, ((Qc + seg * a.P + pix) * a.cs_in + ch + 4) * 4ll > a.in_bytes);             \
         const float4 v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
         ra[j] = (ci0 + 4 * f < a.cs_in) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                              \
     } while (0)
@@ -1749,6 +1703,7 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         const long long Qc = (long long)(c) * WG_KQ;                                                        \
         const int idx = min(tid + 512 * (j), WG_KQ * FG - 1);                                               \
         const int row = idx / FG, f = idx - row * FG;                                                       \
+        MMLF_OOB(OOB_WG_G, ((Qc + a.g_shift + row) * a.cs_g + min(4 * f, a.cs_g - 4) + 4) * 4ll > a.g_bytes); \
         const float4 v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + min(4 * f, a.cs_g - 4)); \
         rg[j] = (4 * f < a.cs_g) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
     } while (0)
@@ -1830,8 +1785,6 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
             _Pragma("unroll") for (int pl = 0; pl < PL; ++pl)                                                 \
                 af[mb][pl] = tr_frag(cur + a_off + pl * A_PLANE + 32 * mb, 4 * ROWA);                        \
         _Pragma("unroll") for (int nb = 0; nb < NBH; ++nb) {                                                 \
-            if (MMLF_PRIO_LEVELS > 1 && (nb == 0 || (nb * MMLF_PRIO_LEVELS) / NBH != ((nb - 1) * MMLF_PRIO_LEVELS) / NBH)) \
-                mmlf_set_prio(MMLF_PRIO_LEVELS - 1 - (nb * MMLF_PRIO_LEVELS) / NBH);                        \
             if (EARLY && (STAGE) && nb == NBH - 2) {                                                         \
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* my staging stores and fragment reads */ \
                 __syncthreads();                                                                             \
@@ -1895,6 +1848,7 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * mb + 4 * q4 + r;      // the ones row (bias gradient) carries no input scale
                 const float un = (ci0 + row == a.cin ? 1.f : sc.inv_sa) * sc.inv_sg;
+                MMLF_OOB(OOB_WG_PART, (long long)(pp - a.part) + (long long)row * NP + 16 * nb + r16 >= a.part_floats);
                 pp[(size_t)row * NP + 16 * nb + r16] = acc[mb][nb][r] * un;
             }
 }
@@ -1974,6 +1928,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float *__r
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+// Compute units the persistent launches size their grids by.  MMLF_CONV_CUS=<n> caps it (multiples of 8 keep the
+// XCD-aware tile order): with n < 256 the conv / weight-gradient grids leave 256 - n CUs without a resident workgroup,
+// which is where a collective's kernels can run BESIDE them under data parallelism (the wide kernels take 151 KB of a
+// CU's 160 KB LDS: nothing else fits on a CU they occupy).  bench.py reports the value in config.conv_cus.
+static int device_cus()
+{
+    static int cus[64] = {};                 // per device ordinal (a benign race only repeats the query)
+    static const int cap = [] { const char *e = getenv("MMLF_CONV_CUS"); return e ? atoi(e) : 0; }();
+    const int dev = current_device();
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cap >= 8 && cap < cus[dev] ? cap : cus[dev];
+}
+extern "C" int mmlf_conv_cus(void) { return device_cus(); }
+
 static int wgrad_nsplit(int nslice)
 {
     int n = 512 / nslice;       // two 256-thread blocks per CU on 256 CUs
@@ -2003,12 +1975,14 @@ static inline bool wgrad16_cfg(int Cin, int Cout, long long nchunks, Wgrad16Cfg 
         // Small batches: ONE round on 256 CUs (42 splits = 252 workgroups at six slices; a third of the partial sums to
         // write and reduce: -2...-4 % per launch at 64 patches, +0.9 % per 64-patch step).  From ~150 patches on, three
         // even rounds of 256 (128 splits) are 0.8 % faster inside the step (profiles/r04_wgrad_nsplit.log).
-        const int one_round = 256 / c->nslice, three_rounds = (768 / c->nslice + 7) / 8 * 8;
+        // (the workspace is sized by the LARGER of the two counts at 256 CUs: a part with fewer CUs only lowers one_round)
+        const int cus = nchunks < 0 ? 256 : (device_cus() < 256 ? device_cus() : 256);
+        const int one_round = cus / c->nslice, three_rounds = (768 / c->nslice + 7) / 8 * 8;
         c->nsplit = nchunks < 0 ? (one_round > three_rounds ? one_round : three_rounds)
                                 : (nchunks >= 42 * 1024 ? three_rounds : one_round);
         static const int forced = [] { const char *e = getenv("MMLF_WGRAD_NSPLIT"); return e ? atoi(e) : 0; }();
         if (forced > 0 && nchunks >= 0)                          // A/B switch (tools/ab_env.sh), inside the sized workspace
-            c->nsplit = forced < three_rounds || forced < one_round ? forced : c->nsplit;
+            c->nsplit = forced <= (three_rounds > one_round ? three_rounds : one_round) ? forced : c->nsplit;
         if (c->nsplit < 8) c->nsplit = 8;
     } else {                     // wgrad4tap_x6n_kernel: two 256-thread workgroups per CU
         c->mb = (c->nb <= 5 && Cin + 1 > 32 && Cin + 1 <= 80) ? 5 : 2;
@@ -2060,15 +2034,26 @@ extern "C" int mmlf_pack_filter(const float *w, float *packed, int Cout, int Cin
     return mmlf_launch_status("mmlf_pack_filter");
 }
 
+// What the ABI's contract says the caller's buffers hold (bytes behind the pointers as passed).  `out` may be a channel
+// slice of a wider buffer (out = base + c_off with c_off + N_store <= cs_out): the bound below is what is left behind the
+// LARGEST such offset, so it never cuts a store the contract allows and never exceeds the allocation.
+static void conv_buffer_bytes(ConvArgs &a, const Grid &g)
+{
+    const long long alloc = grid_alloc_positions(g);
+    a.out_bytes = (alloc * a.cs_out - (a.cs_out - a.n_store)) * 4;
+    a.ref_bytes = a.ref ? alloc * a.cs_ref * 4 : 0;
+    a.in_bytes = alloc * a.cs_in * 4;
+    a.amax_n = amax_entries(g);
+    a.mask_words = g.NQpad / MMLF_TILE * 4096;
+}
+
 template <int NT>
 static int launch_conv(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
     constexpr size_t lds = 2 * (4 * 320 + 4 * 2 * NT * 32) * sizeof(float4);
-    static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_kernel<NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    static PerDeviceOnce attr_once;
+    if (attr_once.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_kernel<NT>), lds, "mmlf_conv2x2"); }))
+        return 1;
     hipLaunchKernelGGL(conv4tap_kernel<NT>, dim3((unsigned)ntiles), dim3(512), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2");
 }
@@ -2088,12 +2073,13 @@ extern "C" int mmlf_conv2x2(const float *in, int cs_in, int K, const float *pack
     Grid g = make_grid(B, H, W);
     MMLF_CHECK_ARG(out_shift >= 0 && out_shift <= g.P + 1, "mmlf_conv2x2: out_shift=%d", out_shift);
     MMLF_CHECK_ARG(!relu_ref || cs_ref >= N_store, "mmlf_conv2x2: cs_ref=%d < N_store", cs_ref);
-    ConvArgs a;
+    ConvArgs a = {};
     a.in = in; a.wp = packed; a.bias = bias; a.out = out; a.ref = relu_ref;
     a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
     a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
     a.divP = make_magic((unsigned)g.P); a.divR = make_magic((unsigned)g.R); a.R = g.R;
     a.relu_mask_out = nullptr; a.relu_mask_in = nullptr;
+    conv_buffer_bytes(a, g);
     MMLF_CHECK_ARG(g.NQpad + g.P + 64 < (1ll << 31), "mmlf_conv2x2: batch x image too large for 32-bit grid positions");
     const long long ntiles = g.NQpad / MMLF_TILE;
     hipStream_t st = (hipStream_t)stream;
@@ -2117,11 +2103,9 @@ template <int MB, int NB, int PL>
 static int launch_wgrad16(const WgradArgs &a, hipStream_t st)
 {
     constexpr size_t lds = 2 * PL * 34 * 32 * (MB | 1) + PL * WG_KQ * 32 * (NB | 1);
-    static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6n_kernel<MB, NB, PL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    static PerDeviceOnce attr_once;
+    if (attr_once.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(wgrad4tap_x6n_kernel<MB, NB, PL>), lds, "mmlf_conv2x2_wgrad_split"); }))
+        return 1;
     hipLaunchKernelGGL((wgrad4tap_x6n_kernel<MB, NB, PL>), dim3(wgrad_grid_blocks(a.nslice, a.nsplit)), dim3(256), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
 }
@@ -2130,11 +2114,9 @@ template <int PL>
 static int launch_wgrad_wide(const WgradArgs &a, hipStream_t st)
 {
     constexpr size_t lds = 2 * (2 * PL * 34 * 32 * (3 | 1) + PL * WG_KQ * 32 * (18 | 1));
-    static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad4tap_x6w_kernel<3, 9, PL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    static PerDeviceOnce attr_once;
+    if (attr_once.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(wgrad4tap_x6w_kernel<3, 9, PL>), lds, "mmlf_conv2x2_wgrad_split(wide)"); }))
+        return 1;
     hipLaunchKernelGGL((wgrad4tap_x6w_kernel<3, 9, PL>), dim3(wgrad_grid_blocks(a.nslice, a.nsplit)), dim3(512), lds, st, a);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_split");
 }
@@ -2196,10 +2178,12 @@ static int wgrad_impl(const float *in, int cs_in, int Cin, const float *g, int c
     MMLF_CHECK_ARG(variant >= 0 && variant <= 2, "mmlf_conv2x2_wgrad: bad variant");
     Grid gr = make_grid(B, H, W);
     MMLF_CHECK_ARG(g_shift >= 0 && g_shift <= gr.P + 1, "mmlf_conv2x2_wgrad: g_shift=%d", g_shift);
-    WgradArgs a;
+    WgradArgs a = {};
     a.in = in; a.g = g; a.part = workspace; a.NQpad = gr.NQpad;
     a.cs_in = cs_in; a.cin = Cin; a.cs_g = cs_g; a.g_shift = g_shift; a.P = gr.P;
     a.in_amax = in_amax; a.g_amax = g_amax; a.chunk_scales = nullptr;
+    a.in_bytes = grid_alloc_positions(gr) * cs_in * 4; a.g_bytes = grid_alloc_positions(gr) * cs_g * 4;
+    a.part_floats = wgrad_partial_floats(Cin, Cout);
     a.nslice = (Cin + 1 + 31) / 32;   // +1: the ones row that yields the bias gradient
     a.nsplit = wgrad_nsplit(a.nslice);
     a.nchunks = (int)(gr.NQpad / WG_KQ);
@@ -2277,18 +2261,6 @@ extern "C" int mmlf_pack_filter_split(const float *w, void *packed, int Cout, in
     return mmlf_launch_status("mmlf_pack_filter_split");
 }
 
-static int device_cus()
-{
-    static int cus[64] = {};                 // per device ordinal (a benign race only repeats the query)
-    const int dev = current_device();
-    if (!cus[dev]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    return cus[dev];
-}
-
 // persistent launches: one workgroup per CU (two for the narrow eight-wave variants), each walks tiles b, b+grid, ...
 static long long conv_split_blocks(int G, long long ntiles, int nw = 8)
 {
@@ -2308,20 +2280,18 @@ static int launch_conv_x6s_epi(const ConvArgs &a, long long ntiles, hipStream_t 
 {
     constexpr size_t lds_pipe = 2 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
     constexpr size_t lds_stats = 8 * (G * 16) * 2 * sizeof(double);
-    static PerDeviceOnce attr_once;   // hipFuncSetAttribute is per device
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_pipe + (PL == 2 ? lds_stats : 0)));
-    }
+    static PerDeviceOnce attr_once;
+    if (attr_once.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI>),
+                                                 lds_pipe + (PL == 2 ? lds_stats : 0), "mmlf_conv2x2_h2"); }))
+        return 1;
     if constexpr (PL == 2 && G == 5) {
         if (a.nw == 16) {
             constexpr size_t lds_stats16 = 16 * (G * 16) * 2 * sizeof(double);
-            static PerDeviceOnce attr_once16;
-            if (attr_once16.first()) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI, 16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MMLF_RING16 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4) + lds_stats16));
-            }
             constexpr size_t lds_pipe16 = MMLF_RING16 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
+            static PerDeviceOnce attr_once16;
+            if (attr_once16.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI, 16>),
+                                                           lds_pipe16 + lds_stats16, "mmlf_conv2x2_h2(16 waves)"); }))
+                return 1;
             const size_t lds16 = lds_pipe16 + (a.bn_partial ? lds_stats16 : 0);
             const long long grid16 = conv_split_blocks(G, ntiles, 16);
             hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI, 16>), dim3((unsigned)grid16), dim3(1024), lds16, st, a, (int)ntiles);
@@ -2363,10 +2333,8 @@ static int launch_conv_rs_epi(const ConvArgs &a, long long ngroups, hipStream_t 
 {
     constexpr size_t lds = (size_t)NCH * 2 * 4 * (G * 16) * 16 + 8 * (G * 16) * 2 * sizeof(double);
     static PerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv4tap_rs_kernel<G, NCH, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    if (attr_once.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_rs_kernel<G, NCH, EPI>), lds, "mmlf_conv2x2_h2(register-streamed)"); }))
+        return 1;
     hipLaunchKernelGGL((conv4tap_rs_kernel<G, NCH, EPI>), dim3((unsigned)conv_rs_blocks(ngroups)), dim3(512), lds, st, a, (int)ngroups);
     return mmlf_launch_status("mmlf_conv2x2_h2(register-streamed)");
 }
@@ -2445,12 +2413,13 @@ static int conv_split_impl(const char *who, int planes, const float *in, int cs_
     MMLF_CHECK_ARG(!relu_ref || cs_ref >= N_store, "%s: cs_ref=%d < N_store", who, cs_ref);
     MMLF_CHECK_ARG((long long)cs_in * 4 * 64 < (1ll << 31), "%s: cs_in too large", who);
     MMLF_CHECK_ARG(planes == 3 || in_amax, "%s: the f16 split needs the input's max |x|", who);
-    ConvArgs a;
+    ConvArgs a = {};
     a.in = in; a.wp = reinterpret_cast<const float *>(packed); a.bias = bias; a.out = out; a.ref = relu_ref;
     a.NQ = g.NQ; a.cs_in = cs_in; a.nchunk = cs_in / 8; a.cs_out = cs_out; a.n_store = N_store; a.n_true = N;
     a.out_shift = out_shift; a.vh = vh; a.vw = vw; a.P = g.P; a.G = g.G; a.relu = relu; a.cs_ref = cs_ref;
     a.in_amax = in_amax; a.out_amax = out_amax; a.bn_partial = bn_partial;
     a.relu_mask_out = relu_mask_out; a.relu_mask_in = relu_mask_in;
+    conv_buffer_bytes(a, g);
     MMLF_CHECK_ARG(!bn_partial || (planes == 2 && N_store >= N), "%s: BatchNorm statistics need the f16 split path", who);
     // the f16-packed filter ends with its columns' unscale factors
     a.w_unscale = planes == 2 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(packed) +
@@ -2794,4 +2763,98 @@ extern "C" int mmlf_conv2x2_wgrad_thin(const float *in, int cs_in, int Cin, cons
     hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((total + 3) / 4), dim3(256), 0, st, workspace, gw_oihw, gb, Cin, Cout,
                        Cin + 1, THIN_MAXN, nwaves, variant, accumulate);
     return mmlf_launch_status("mmlf_conv2x2_wgrad_thin");
+}
+
+// ---------------------------------------------------------------------------------------------
+// what this binary is (round 5): every build switch that changes behaviour, in one string; the loader refuses a
+// result-changing build unless told otherwise (mmlf_amd/_lib.py), bench.py prints the string in its line
+// ---------------------------------------------------------------------------------------------
+#ifndef MMLF_GIT_HASH
+#define MMLF_GIT_HASH "unknown"
+#endif
+#ifdef MMLF_BOUNDS_DEBUG
+#define MMLF_BOUNDS_DEBUG_VALUE 1
+#else
+#define MMLF_BOUNDS_DEBUG_VALUE 0
+#endif
+extern "C" int mmlf_build_is_ablation(void) { return (MMLF_ABL_TERMS != 3 || MMLF_ABL_WGRAD_STAGE != 0) ? 1 : 0; }
+extern "C" const char *mmlf_build_info(void)
+{
+    static char text[320];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        snprintf(text, sizeof(text),
+                 "abi=%d git=%s MMLF_ABL_TERMS=%d MMLF_ABL_WGRAD_STAGE=%d MMLF_GRID_PAD_W=%d MMLF_GRID_PAD_H=%d MMLF_RING16=%d "
+                 "MMLF_WGRAD_EARLY=%d MMLF_BOUNDS_DEBUG=%d ablation=%d",
+                 MMLF_ABI_VERSION, MMLF_GIT_HASH, MMLF_ABL_TERMS, MMLF_ABL_WGRAD_STAGE, MMLF_GRID_PAD_W, MMLF_GRID_PAD_H,
+                 MMLF_RING16, MMLF_WGRAD_EARLY, MMLF_BOUNDS_DEBUG_VALUE, mmlf_build_is_ablation());
+    });
+    return text;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bounds audit (round 5).  For one launch of the given shape: the END (largest byte offset + 1) of what the launch may
+// read or write behind each pointer argument, derived here from the same launch geometry the entry points compute
+// (window pieces, tile counts, grids).  tests/test_bounds_audit.py holds every end against what the size queries of this
+// ABI tell the caller to allocate, over a sweep of shapes; the -DMMLF_BOUNDS_DEBUG build counts violations on the GPU.
+// Derivations (positions are grid positions q; a buffer of channel stride cs holds alloc = NQpad + P + 72 of them):
+//  conv, f16 split: the activation window of the LAST tile (first position NQpad - TILE) ends at position
+//    NQpad + P (one contiguous window of TILE + 1 + P positions, or two segments whose second one ends at P + 256);
+//    the last piece fetches a_tail positions only, the other lanes re-fetch the last of those.  The register-streamed
+//    kernel reads positions Q0 + 32 w + 16 mb + r16 + {0, 1, P, P + 1}: the same end.  Output: position q + out_shift,
+//    q < NQpad, n_store channels; the ReLU reference likewise.  Row maxima: rows up to the one behind the last position
+//    read (input) / written (output).  Mask words: [tile][8][8][64].  Statistics: [workgroup][2][N] doubles.
+//  weight gradient: chunk c stages in[32 c .. 32 c + 32 + P] and g[32 c + g_shift .. + 31], c < NQpad / 32.
+// ---------------------------------------------------------------------------------------------
+extern "C" int mmlf_audit_conv_h2(int cs_in, int K, int N, int cs_out, int N_store, int out_shift, int cs_ref, int B, int H, int W,
+                                  int64_t *ends /* [MMLF_AUDIT_CONV_N] */)
+{
+    const int np = x6_np(N);
+    MMLF_CHECK_ARG(np > 0 && K > 0 && (K + 7) / 8 * 8 == cs_in && B > 0 && H > 0 && W > 0 && ends, "mmlf_audit_conv_h2: bad argument");
+    const Grid g = make_grid(B, H, W);
+    const int nw = conv_sixteen_waves(2, np, g) ? 16 : 8;
+    const int tile = 32 * nw, nchunk = cs_in / 8;
+    // the last activation position a launch fetches
+    long long last_in;
+    if (conv_rs_shape(2, np, nchunk, nw)) {
+        last_in = (g.NQpad - MMLF_TILE) + 32 * 7 + 16 + 15 + g.P + 1;
+    } else if (g.P + tile + 1 <= 640) {
+        const int pieces = (g.P + tile + 1 + 31) / 32, tail = (g.P + tile + 1) - 32 * (pieces - 1);
+        last_in = (g.NQpad - tile) + 32 * (pieces - 1) + tail - 1;
+    } else {
+        last_in = (g.NQpad - tile) + 320 + 32 * 8 + (g.P - 320) + 0;        // segment 1, piece 8, one position
+    }
+    const long long last_out = g.NQpad - 1 + out_shift;
+    const long long blocks = mmlf_conv2x2_blocks(K, N, B, H, W);
+    ends[0] = (last_in + 1) * cs_in * 4;                                      // in
+    ends[1] = (int64_t)nchunk * 8 * np * 16 + (int64_t)np * 4;                // packed (planes, then the columns' 1 / scale)
+    ends[2] = (int64_t)N * 4;                                                 // bias
+    ends[3] = (last_out * cs_out + N_store) * 4;                              // out
+    ends[4] = cs_ref ? (last_out * cs_ref + N_store) * 4 : 0;                 // relu_ref
+    ends[5] = (MMLF_AMAX_HEAD + ((g.NQ - 1) / g.P + 1) + 1) * 4;              // in_amax: rows read by the last valid wave, + 1
+    ends[6] = (MMLF_AMAX_HEAD + last_out / g.P + 1) * 4;                      // out_amax
+    ends[7] = blocks * 2 * N * 8;                                             // bn_partial (doubles)
+    ends[8] = g.NQpad / MMLF_TILE * 4096 * 4;                                 // relu mask words (in or out)
+    return 0;
+}
+
+extern "C" int mmlf_audit_wgrad_h2(int cs_in, int Cin, int cs_g, int Cout, int g_shift, int B, int H, int W,
+                                   int64_t *ends /* [MMLF_AUDIT_WGRAD_N] */)
+{
+    Wgrad16Cfg c;
+    MMLF_CHECK_ARG(B > 0 && H > 0 && W > 0 && ends && Cin > 0 && Cout > 0, "mmlf_audit_wgrad_h2: bad argument");
+    const Grid g = make_grid(B, H, W);
+    const long long nchunks = g.NQpad / WG_KQ;
+    MMLF_CHECK_ARG(wgrad16_cfg(Cin, Cout, nchunks, &c), "mmlf_audit_wgrad_h2: Cout=%d", Cout);
+    const long long last_c = (nchunks - 1) * WG_KQ;
+    ends[0] = (last_c + g.P + 32 + 1) * cs_in * 4;                            // in: segment 1, row 32
+    ends[1] = (last_c + g_shift + 31 + 1) * cs_g * 4;                         // g
+    ends[2] = (int64_t)Cout * Cin * 4 * 4;                                    // gw (OIHW)
+    ends[3] = (int64_t)Cout * 4;                                              // gb
+    ends[4] = ((int64_t)c.nsplit * 4 * (c.nslice * 16 * c.mb) * (16 * c.nb)   // workspace: partial sums of this launch ...
+               > wgrad_partial_floats(Cin, Cout) ? -1                           // (must fit the sized region: else the scales overlap them)
+               : wgrad_partial_floats(Cin, Cout) + 2 * nchunks + 2) * 4;        // ... then the per-chunk and the two tensor scales
+    ends[5] = (MMLF_AMAX_HEAD + amax_rows(g)) * 4;                            // in_amax (the scale kernel clamps rows to amax_rows - 1)
+    ends[6] = ends[5];                                                        // g_amax
+    return 0;
 }
