@@ -114,7 +114,10 @@ __device__ __forceinline__ int mmlf_records_left(long long total, long long off)
 #endif
 #ifndef MMLF_ABL_WGRAD_STAGE
 #define MMLF_ABL_WGRAD_STAGE 0   // wide weight gradient, timing ablations of its staging (WRONG results): 1 = the gradient tile
-#endif                           // is stored unsplit (no vector work on it); 2 = it is not staged at all after the first chunk
+#endif                           // is stored unsplit (loads and LDS stores stay, no vector work on it: what a producer-side split
+                                 // could save at most); 2 = it is neither loaded nor stored after the first chunk (what staging
+                                 // it ONCE per chunk for all six slices could save at most); 3 = nothing is staged after the first
+                                 // chunk (matrix instructions, fragment reads and the barrier alone)
 #ifndef MMLF_RING16
 #define MMLF_RING16 3   // pipeline depth of the sixteen-wave conv variant (LDS: 30 KB per buffer + 20 KB; 4 measures the same)
 #endif
@@ -488,6 +491,131 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs &a, const f32x4 (
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// TRANSPOSED epilogue (round 5).  The MFMA is symmetric in its two operands: with the weights as the A operand and the
+// activations as B the same instruction yields the transposed tile -- lane (r16, q4) then holds FOUR CONSECUTIVE CHANNELS
+// 16 nb + 4 q4 + r of ONE position 16 mb + r16 per accumulator tile instead of one channel of four positions.  What that buys:
+//  * the tile is stored with 16-byte instructions (the four lanes of a position write 64 consecutive bytes): 2 G store
+//    instructions per wave and tile instead of 8 G.  The epilogue's store tail is bound by the ISSUE of its vector-memory
+//    instructions, not by their bytes (round 2: all eight waves stand in it at once and the matrix cores idle meanwhile);
+//  * a position's validity / ReLU bits are per lane and row block, not per value: the row mask is two bits per lane,
+//    the ReLU mask words hold (nb, r) as bit 4 (nb % 8) + r of word nb / 8: 2 ceil(G / 8) words per lane instead of 8
+//    (a third of the mask traffic on the 280-wide layers, a quarter on the 70-wide ones);
+//  * bias and weight-unscale of a lane's four channels are two ds_read_b128 from a table the workgroup put into LDS once
+//    per launch (global loads between the stores made every column block wait for all stores issued so far).
+// The values are formed exactly as in conv_epilogue16 -- fma(acc * unscale_a, uw, bias), one rounding -- so the two
+// orientations write the same bits (tests/test_gpu_kernels.py::test_transposed_epilogue_writes_the_same_bits).
+// Launch kinds: plain, ReLU, ReLU + mask-out, mask-in (three of a training block's four convolution launches); the
+// statistics kind keeps conv_epilogue16 (its sums run over positions = along a lane's registers there, across lanes here).
+// Needs n_store % 4 == 0 and a 16-byte aligned `out` (the host checks; channel slices at odd offsets take the other form).
+// ---------------------------------------------------------------------------------------------
+template <int G> constexpr int tr_mask_words() { return (G + 7) / 8; }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int G, int EPI>
+__device__ __forceinline__ void conv_epilogue16_tr(const ConvArgs &a, const f32x4 (&acc)[2][G], long long Q0, int w,
+                                                   int r16, int q4, float unscale_a, float &run_max,
+                                                   const float *coef /* LDS: [16 G] weight-unscale, [16 G] bias */)
+{
+    static_assert(EPI >= 0 && !(EPI & (EPI_STATS | EPI_REF_IN)), "kinds of the transposed epilogue");
+    constexpr int NP = 16 * G, MW = tr_mask_words<G>();
+    constexpr bool do_relu = (EPI & EPI_RELU) != 0, mask_out = (EPI & EPI_MASK_OUT) != 0, use_bits = (EPI & EPI_BITS_IN) != 0;
+    const unsigned m = wave_row_mask(a, Q0, w, r16 + 16 * q4);      // bit p: position p of the wave's 32 is a valid output
+    const long long qb = Q0 + 32 * w + a.out_shift;                   // wave-uniform
+    const int ob_left = mmlf_records_left(a.out_bytes, qb * a.cs_out * 4ll);
+    const __amdgpu_buffer_rsrc_t ob =
+        __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)qb * a.cs_out, 0, ob_left, MMLF_BUF_FLAGS);
+    unsigned lo = ((unsigned)r16 * a.cs_out + 4u * q4) * 4u;
+    asm volatile("" : "+v"(lo));             // (tile-invariant: kept out of the persistent loop's registers, see conv_epilogue)
+    const size_t mbase = ((size_t)(Q0 / MMLF_TILE) * 8 + w) * 512 + (r16 + 16 * q4);
+    unsigned mw[2][MW];
+    bool ok[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        ok[mb] = (m >> (16 * mb + r16) & 1u) != 0;
+#pragma unroll
+        for (int j = 0; j < MW; ++j) {
+            mw[mb][j] = use_bits ? a.relu_mask_in[mbase + 64 * (MW * mb + j)] : 0u;
+            if (use_bits && !ok[mb]) mw[mb][j] = 0u;        // an invalid position keeps nothing
+        }
+    }
+    MMLF_OOB(OOB_MASK, (use_bits || mask_out) && (long long)mbase + 64 * (2 * MW - 1) >= a.mask_words);
+    float mk[2] = {0.f, 0.f};                 // max |out| of this lane's two positions
+    // the table values of column block nb + 1 are requested while block nb is worked on; the fences keep the scheduler from
+    // pulling ALL blocks' reads to the front (8 registers per block: the wide kernel has none to spare)
+    const float *cl = coef + 4 * q4;
+    f32x4 uw_n = *reinterpret_cast<const f32x4 *>(cl), b_n = *reinterpret_cast<const f32x4 *>(cl + NP);
+#pragma unroll
+    for (int nb = 0; nb < G; ++nb) {
+        const int c0 = 16 * nb + 4 * q4;
+        const f32x4 uw4 = uw_n, b4 = b_n;
+        if (nb + 1 < G) {
+            uw_n = *reinterpret_cast<const f32x4 *>(cl + 16 * (nb + 1));
+            b_n = *reinterpret_cast<const f32x4 *>(cl + NP + 16 * (nb + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            u32x4 st;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaf(acc[mb][nb][r] * unscale_a, uw4[r], b4[r]);   // the products are exact (powers of two): one rounding
+                if (do_relu) v = fmaxf(v, 0.f);
+                if (use_bits) {              // 0 or ~0 from the bit: two instructions per value
+                    const int keep = ((int)(mw[mb][nb >> 3] << (31 - (4 * (nb & 7) + r)))) >> 31;
+                    v = __uint_as_float(__float_as_uint(v) & (unsigned)keep);
+                } else {
+                    v = ok[mb] ? v : 0.f;
+                }
+                if (mask_out) mw[mb][nb >> 3] |= (v > 0.f ? 1u : 0u) << (4 * (nb & 7) + r);
+                asm("v_max_f32 %0, %1, |%2|" : "=v"(mk[mb]) : "v"(mk[mb]), "v"(v));
+                st[r] = __float_as_uint(v);
+            }
+            if (c0 < a.n_store) {
+                MMLF_OOB(OOB_OUT, (long long)lo + 64 * nb + (long long)(16 * mb) * a.cs_out * 4 + 12 >= ob_left);
+                __builtin_amdgcn_raw_buffer_store_b128(st, ob, lo + 64 * nb, (unsigned)(16 * mb) * a.cs_out * 4u, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (mask_out) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int j = 0; j < MW; ++j) a.relu_mask_out[mbase + 64 * (MW * mb + j)] = mw[mb][j];
+    }
+    if (a.out_amax) {
+        const unsigned d0 = (unsigned)qb;                       // first destination position of the wave
+        const unsigned rd0 = fastdiv(d0, a.divP);
+        const int nfirst = (int)((rd0 + 1) * (unsigned)a.P - d0);   // wave positions [0, nfirst) lie in grid row rd0
+        float m_lo = 0.f, m_hi = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            if (16 * mb + r16 < nfirst) m_lo = fmaxf(m_lo, mk[mb]);
+            else m_hi = fmaxf(m_hi, mk[mb]);
+        }
+        m_lo = mmlf_wave_max(m_lo);
+        m_hi = mmlf_wave_max(m_hi);
+        if (r16 + 16 * q4 == 0) {
+            MMLF_OOB(OOB_AMAX, MMLF_AMAX_HEAD + (long long)fastdiv(d0 + 31, a.divP) >= a.amax_n);
+            if (m_lo > 0.f) mmlf_amax_raise_nowait(a.out_amax + MMLF_AMAX_HEAD + rd0, m_lo);
+            if (m_hi > 0.f) {
+                const unsigned rdl = fastdiv(d0 + 31, a.divP);
+                for (unsigned r = rd0 + 1; r <= rdl; ++r) mmlf_amax_raise_nowait(a.out_amax + MMLF_AMAX_HEAD + r, m_hi);
+            }
+            run_max = fmaxf(run_max, fmaxf(m_lo, m_hi));        // lane 0 carries the tensor maximum
+        }
+    }
+}
+// the workgroup's table of per-column weight-unscale and bias values (transposed epilogue), filled once per launch
+template <int NP>
+__device__ __forceinline__ void conv_fill_coef(const ConvArgs &a, float *coef, int tid, int nthreads)
+{
+    for (int k = tid; k < NP; k += nthreads) {
+        coef[k] = a.w_unscale ? a.w_unscale[k] : 1.f;
+        coef[NP + k] = (a.bias && k < a.n_true) ? a.bias[k] : 0.f;
+    }
+}
+
 // f16 split: the power-of-two scale wave w of tile Q0 applies to its activation operand.  The wave's valid
 // outputs q read in[q + {0, 1, P, P+1}], i.e. grid rows row(q0) .. row(q0 + 31) + 1 (no row is added behind a
 // patch's last row: its outputs are never valid), so the scale comes from those rows' maxima alone: a wave's
@@ -548,7 +676,8 @@ __device__ __forceinline__ ConvArgs late_args()
 // 39 %, the weights are fetched once per 512 positions, and more activation bytes are in flight per CU -- these launches
 // are bound by memory concurrency, not by the matrix cores).  Layouts (masks, statistics, scales) are indexed by the
 // global 32-position group, so the two variants produce the same bytes.
-template <int G, int PL, int EPI = EPI_GENERIC, int NW = 8>
+// TR: transposed accumulator tiles and epilogue (conv_epilogue16_tr above).
+template <int G, int PL, int EPI = EPI_GENERIC, int NW = 8, bool TR = false>
 __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4tap_x6s_kernel(ConvArgs a, int ntiles)
 {
     constexpr int NP = G * 16;
@@ -688,9 +817,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
     int ntile = tile, nc = 0;              // chunk being fetched (one ahead)
     if (tile >= ntiles) return;
     // optional BatchNorm statistics of the output: per-wave double sums behind the two pipeline buffers
+    // behind the pipeline buffers: the transposed epilogue's per-column table (TR), or the statistics' per-wave double sums
+    float *coef = reinterpret_cast<float *>(lds + D * BUF_F4);               // [2][NP]
     double *stats_all = reinterpret_cast<double *>(lds + D * BUF_F4);        // [NW waves][NP][2]
-    if (late_args().bn_partial)
-        for (int k = tid; k < NW * NP * 2; k += 64 * NW) stats_all[k] = 0.0;  // ordered by the barrier below
+    if constexpr (TR) conv_fill_coef<NP>(late_args(), coef, tid, 64 * NW);   // ordered by the barrier below
+    else if (late_args().bn_partial)
+        for (int k = tid; k < NW * NP * 2; k += 64 * NW) stats_all[k] = 0.0;
     // f16 split: operand scales (powers of two) and what undoes them in the epilogue
     float scale_a = 1.f, unscale_a = 1.f, run_max = 0.f;
     if constexpr (PL == 2) {
@@ -807,8 +939,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asp[mb][pa], bq[g % 3][pb], acc[mb][g], 0, 0, 0)
 #define H2_TERM(pa, pb)                                                                                      \
     _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
-        acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),          \
-                                                            __builtin_bit_cast(f16x8, bq[g % 3][pb]), acc[mb][g], 0, 0, 0)
+        acc[mb][g] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bq[g % 3][pb]),   \
+                                                                 __builtin_bit_cast(f16x8, asp[mb][pa]), acc[mb][g], 0, 0, 0) \
+                        : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),     \
+                                                                 __builtin_bit_cast(f16x8, bq[g % 3][pb]), acc[mb][g], 0, 0, 0)
             if constexpr (PL == 3) {
                 X6_TERM(2, 0);
                 X6_TERM(0, 2);
@@ -837,8 +971,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             if constexpr (PL == 2)
                 if (tile + (int)gridDim.x < ntiles)
                     next_amax = wave_operand_amax_gather(e, (long long)(tile + gridDim.x) * TILE, w, lane);
-            conv_epilogue16<G, EPI>(e, acc, (long long)tile * TILE, w, r16, q4, unscale_a, run_max,
-                               e.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
+            if constexpr (TR)
+                conv_epilogue16_tr<G, EPI>(e, acc, (long long)tile * TILE, w, r16, q4, unscale_a, run_max, coef);
+            else
+                conv_epilogue16<G, EPI>(e, acc, (long long)tile * TILE, w, r16, q4, unscale_a, run_max,
+                                        e.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -904,7 +1041,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
 // Layouts (mask words, statistics, amax, scales) are indexed by the global 32-position group exactly as in
 // conv4tap_x6s_kernel (tile = group / 8, wave = group % 8): the two kernels write the same bytes.
 // ---------------------------------------------------------------------------------------------
-template <int G, int NCH, int EPI>
+template <int G, int NCH, int EPI, bool TR = false>
 __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngroups)
 {
     constexpr int NP = G * 16;
@@ -926,8 +1063,10 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
 
     for (int o = tid * 16; o < WBYTES; o += 512 * 16)
         *reinterpret_cast<uint4 *>(smem + o) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(a.wp) + o);
-    double *stats_all = reinterpret_cast<double *>(smem + WBYTES);            // [8 waves][NP][2]
-    if (a.bn_partial)
+    float *coef = reinterpret_cast<float *>(smem + WBYTES);                   // transposed epilogue: [2][NP]
+    double *stats_all = reinterpret_cast<double *>(smem + WBYTES);            // statistics: [8 waves][NP][2]
+    if constexpr (TR) conv_fill_coef<NP>(a, coef, tid, 512);
+    else if (a.bn_partial)
         for (int k = tid; k < 8 * NP * 2; k += 512) stats_all[k] = 0.0;
     __syncthreads();
 
@@ -1026,8 +1165,10 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
                 }
 #define RS_TERM(pa, pb)                                                                                      \
     _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                                         \
-        acc[mb][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),          \
-                                                            __builtin_bit_cast(f16x8, bq[idx % 3][pb]), acc[mb][g], 0, 0, 0)
+        acc[mb][g] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bq[idx % 3][pb]), \
+                                                                 __builtin_bit_cast(f16x8, asp[mb][pa]), acc[mb][g], 0, 0, 0) \
+                        : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, asp[mb][pa]),     \
+                                                                 __builtin_bit_cast(f16x8, bq[idx % 3][pb]), acc[mb][g], 0, 0, 0)
                 RS_TERM(1, 0);
                 RS_TERM(0, 1);
                 RS_TERM(0, 0);
@@ -1036,8 +1177,11 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
         }
         // (round 4 also measured this epilogue with ROW stores -- values through a wave-private LDS image, 16-byte stores of
         // consecutive addresses, 1 KB per wave instruction instead of 64-byte segments: 0.96-1.0 ms either way, removed)
-        conv_epilogue16<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max,
-                                a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
+        if constexpr (TR)
+            conv_epilogue16_tr<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max, coef);
+        else
+            conv_epilogue16<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max,
+                                    a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -1686,7 +1830,11 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
 
     float4 ra[NA], rg[NG];
     // staging items are clamped to the last one instead of predicated: surplus threads load and store that
-    // item again (same value), which keeps the loop free of divergent branches
+    // item again (same value), which keeps the loop free of branches.  Also of SCALAR ones: round 5 let the waves whose
+    // items of a piece are all surplus (3 of 8 on the second activation piece, 4 of 8 on the fifth gradient piece at <3, 9>)
+    // skip the piece -- less work, no 64 lanes storing to one LDS address -- and the launch took 8.53 ms instead of 8.17
+    // (profiles/r05_kbench_wgrad_surplus.log): a branch per column block ends the basic block the MFMAs and the staging
+    // instructions are interleaved in.
 #define WW_GLOAD_A(j, c)                                                                                    \
     do {                                                                                                    \
         const long long Qc = (long long)(c) * WG_KQ;                                                        \
@@ -1729,7 +1877,13 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     do {                                                                                                    \
         const int idx = min(tid + 512 * (j), WG_KQ * FG - 1);                                               \
         const int row = idx / FG, f = idx - row * FG;                                                       \
-        split_store4_pl<PL>(rg[j], st_sg, (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);                   \
+        if (MMLF_ABL_WGRAD_STAGE == 1 && PL == 2) {      /* ablation: the same bytes, no split */            \
+            char *p0_ = (dst) + A_BYTES + row * ROWG + 8 * f;                                               \
+            *reinterpret_cast<uint2 *>(p0_) = make_uint2(__float_as_uint(rg[j].x), __float_as_uint(rg[j].y)); \
+            *reinterpret_cast<uint2 *>(p0_ + G_PLANE) = make_uint2(__float_as_uint(rg[j].z), __float_as_uint(rg[j].w)); \
+        } else {                                                                                            \
+            split_store4_pl<PL>(rg[j], st_sg, (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);               \
+        }                                                                                                   \
     } while (0)
 
     const int tq = (lane & 15) >> 2, tp = lane & 3;
@@ -1801,11 +1955,15 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
             }                                                                                                \
             if (STAGE) {                                                                                     \
                 if (nb < NA) {                                                                               \
-                    WW_STORE_A(nb < NA ? nb : 0, nxt);                                                       \
-                    if (RELOAD) WW_GLOAD_A(nb < NA ? nb : 0, c + 2);                                         \
+                    if (MMLF_ABL_WGRAD_STAGE < 3) {                                                          \
+                        WW_STORE_A(nb < NA ? nb : 0, nxt);                                                   \
+                        if (RELOAD) WW_GLOAD_A(nb < NA ? nb : 0, c + 2);                                     \
+                    }                                                                                        \
                 } else if (nb - NA < NG) {                                                                   \
-                    WW_STORE_G(nb - NA < NG ? nb - NA : 0, nxt);                                             \
-                    if (RELOAD) WW_GLOAD_G(nb - NA < NG ? nb - NA : 0, c + 2);                               \
+                    if (MMLF_ABL_WGRAD_STAGE < 2) {                                                          \
+                        WW_STORE_G(nb - NA < NG ? nb - NA : 0, nxt);                                         \
+                        if (RELOAD) WW_GLOAD_G(nb - NA < NG ? nb - NA : 0, c + 2);                           \
+                    }                                                                                        \
                 }                                                                                            \
             }                                                                                                \
             _Pragma("unroll") for (int term = (PL == 3 ? 0 : 3 - MMLF_ABL_TERMS); term < (PL == 3 ? 6 : 3); ++term) \
@@ -2275,32 +2433,46 @@ static bool conv_sixteen_waves(int planes, int np, const Grid &g)
     return on && planes == 2 && np == 80 && g.P + 513 <= 640;
 }
 
-template <int G, int PL, int EPI>
+// The transposed epilogue (conv_epilogue16_tr) serves the launch kinds plain / ReLU / ReLU + mask-out / mask-in when the
+// output rows can take 16-byte stores.  MMLF_CONV_TR=0 turns it off for the whole process (A/B; the ReLU mask words then
+// have the other layout, for their producer and their consumer alike).
+static bool conv_tr_enabled()
+{
+    static const int on = [] { const char *e = getenv("MMLF_CONV_TR"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+static bool conv_tr_fits(const ConvArgs &a)
+{
+    return a.n_store % 4 == 0 && a.cs_out % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+}
+
+template <int G, int PL, int EPI, bool TR = false>
 static int launch_conv_x6s_epi(const ConvArgs &a, long long ntiles, hipStream_t st)
 {
     constexpr size_t lds_pipe = 2 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
     constexpr size_t lds_stats = 8 * (G * 16) * 2 * sizeof(double);
+    constexpr size_t lds_coef = 2 * (G * 16) * sizeof(float);
     static PerDeviceOnce attr_once;
-    if (attr_once.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI>),
-                                                 lds_pipe + (PL == 2 ? lds_stats : 0), "mmlf_conv2x2_h2"); }))
+    if (attr_once.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI, 8, TR>),
+                                                 lds_pipe + (TR ? lds_coef : PL == 2 ? lds_stats : 0), "mmlf_conv2x2_h2"); }))
         return 1;
     if constexpr (PL == 2 && G == 5) {
         if (a.nw == 16) {
             constexpr size_t lds_stats16 = 16 * (G * 16) * 2 * sizeof(double);
             constexpr size_t lds_pipe16 = MMLF_RING16 * (2 * 640 + 4 * PL * G * 16) * sizeof(float4);
             static PerDeviceOnce attr_once16;
-            if (attr_once16.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI, 16>),
-                                                           lds_pipe16 + lds_stats16, "mmlf_conv2x2_h2(16 waves)"); }))
+            if (attr_once16.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_x6s_kernel<G, PL, EPI, 16, TR>),
+                                                           lds_pipe16 + (TR ? lds_coef : lds_stats16), "mmlf_conv2x2_h2(16 waves)"); }))
                 return 1;
-            const size_t lds16 = lds_pipe16 + (a.bn_partial ? lds_stats16 : 0);
+            const size_t lds16 = lds_pipe16 + (TR ? lds_coef : a.bn_partial ? lds_stats16 : 0);
             const long long grid16 = conv_split_blocks(G, ntiles, 16);
-            hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI, 16>), dim3((unsigned)grid16), dim3(1024), lds16, st, a, (int)ntiles);
+            hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI, 16, TR>), dim3((unsigned)grid16), dim3(1024), lds16, st, a, (int)ntiles);
             return mmlf_launch_status("mmlf_conv2x2_h2(16 waves)");
         }
     }
-    const size_t lds = lds_pipe + (a.bn_partial ? lds_stats : 0);
+    const size_t lds = lds_pipe + (TR ? lds_coef : a.bn_partial ? lds_stats : 0);
     const long long grid = conv_split_blocks(G, ntiles);
-    hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI>), dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
+    hipLaunchKernelGGL((conv4tap_x6s_kernel<G, PL, EPI, 8, TR>), dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
     return mmlf_launch_status(PL == 3 ? "mmlf_conv2x2_split" : "mmlf_conv2x2_h2");
 }
 
@@ -2328,29 +2500,40 @@ static long long conv_rs_blocks(long long ngroups)
     const long long grid = device_cus(), need = (ngroups + 7) / 8;
     return grid > need ? need : grid;
 }
-template <int G, int NCH, int EPI>
+template <int G, int NCH, int EPI, bool TR = false>
 static int launch_conv_rs_epi(const ConvArgs &a, long long ngroups, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)NCH * 2 * 4 * (G * 16) * 16 + 8 * (G * 16) * 2 * sizeof(double);
+    constexpr size_t lds = (size_t)NCH * 2 * 4 * (G * 16) * 16 + (TR ? 2 * (G * 16) * sizeof(float) : 8 * (G * 16) * 2 * sizeof(double));
     static PerDeviceOnce attr_once;
-    if (attr_once.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_rs_kernel<G, NCH, EPI>), lds, "mmlf_conv2x2_h2(register-streamed)"); }))
+    if (attr_once.run([] { return mmlf_allow_lds(reinterpret_cast<const void *>(conv4tap_rs_kernel<G, NCH, EPI, TR>), lds, "mmlf_conv2x2_h2(register-streamed)"); }))
         return 1;
-    hipLaunchKernelGGL((conv4tap_rs_kernel<G, NCH, EPI>), dim3((unsigned)conv_rs_blocks(ngroups)), dim3(512), lds, st, a, (int)ngroups);
+    hipLaunchKernelGGL((conv4tap_rs_kernel<G, NCH, EPI, TR>), dim3((unsigned)conv_rs_blocks(ngroups)), dim3(512), lds, st, a, (int)ngroups);
     return mmlf_launch_status("mmlf_conv2x2_h2(register-streamed)");
 }
+// launch kind -> epilogue build.  tr: the transposed form, for the kinds that have one
+// (TR_PLAIN: whether the plain kind has one too -- on the 80-column kernels it measured 3 % slower: profiles/r05_kbench_tr.log)
+#define MMLF_CONV_KIND_SWITCH(LAUNCH, TR_PLAIN, ...)                                                                              \
+    do {                                                                                                                \
+        const int kind = (a.relu ? EPI_RELU : 0) | (a.bn_partial ? EPI_STATS : 0) | (a.relu_mask_in ? EPI_BITS_IN : 0) | \
+                         (a.ref ? EPI_REF_IN : 0) | (a.relu_mask_out ? EPI_MASK_OUT : 0);                               \
+        const bool tr = conv_tr_enabled() && conv_tr_fits(a);                                                           \
+        if ((a.relu_mask_in || a.relu_mask_out) && conv_tr_enabled() && !tr)                                            \
+            return mmlf_fail("mmlf_conv2x2_h2: ReLU mask words need n_store %% 4 == 0 and a 16-byte aligned output");   \
+        switch (kind) {                                                                                                 \
+        case EPI_PLAIN: return tr && TR_PLAIN ? LAUNCH<__VA_ARGS__, EPI_PLAIN, true>(a, n, st) : LAUNCH<__VA_ARGS__, EPI_PLAIN>(a, n, st); \
+        case EPI_RELU: return tr ? LAUNCH<__VA_ARGS__, EPI_RELU, true>(a, n, st) : LAUNCH<__VA_ARGS__, EPI_RELU>(a, n, st); \
+        case EPI_RELU | EPI_MASK_OUT:                                                                                   \
+            return tr ? LAUNCH<__VA_ARGS__, EPI_RELU | EPI_MASK_OUT, true>(a, n, st) : LAUNCH<__VA_ARGS__, EPI_RELU | EPI_MASK_OUT>(a, n, st); \
+        case EPI_BITS_IN: return tr ? LAUNCH<__VA_ARGS__, EPI_BITS_IN, true>(a, n, st) : LAUNCH<__VA_ARGS__, EPI_BITS_IN>(a, n, st); \
+        case EPI_STATS: return LAUNCH<__VA_ARGS__, EPI_STATS>(a, n, st);                                                \
+        default: break;                                                                                                 \
+        }                                                                                                               \
+    } while (0)
 template <int G, int NCH>
-static int launch_conv_rs(const ConvArgs &a, long long ngroups, hipStream_t st)
+static int launch_conv_rs(const ConvArgs &a, long long n, hipStream_t st)
 {
-    const int kind = (a.relu ? EPI_RELU : 0) | (a.bn_partial ? EPI_STATS : 0) | (a.relu_mask_in ? EPI_BITS_IN : 0) |
-                     (a.ref ? EPI_REF_IN : 0) | (a.relu_mask_out ? EPI_MASK_OUT : 0);
-    switch (kind) {
-    case EPI_PLAIN: return launch_conv_rs_epi<G, NCH, EPI_PLAIN>(a, ngroups, st);
-    case EPI_RELU: return launch_conv_rs_epi<G, NCH, EPI_RELU>(a, ngroups, st);
-    case EPI_RELU | EPI_MASK_OUT: return launch_conv_rs_epi<G, NCH, EPI_RELU | EPI_MASK_OUT>(a, ngroups, st);
-    case EPI_STATS: return launch_conv_rs_epi<G, NCH, EPI_STATS>(a, ngroups, st);
-    case EPI_BITS_IN: return launch_conv_rs_epi<G, NCH, EPI_BITS_IN>(a, ngroups, st);
-    default: return launch_conv_rs_epi<G, NCH, EPI_GENERIC>(a, ngroups, st);
-    }
+    MMLF_CONV_KIND_SWITCH(launch_conv_rs_epi, false, G, NCH);
+    return launch_conv_rs_epi<G, NCH, EPI_GENERIC>(a, n, st);
 }
 
 // the launch kinds of a training step get their own epilogue build on the hot shapes (f16 split, 70- and 280-wide
@@ -2365,18 +2548,12 @@ static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
         }
     }
     if constexpr (PL == 2 && (G == 5 || G == 18)) {
-        const int kind = (a.relu ? EPI_RELU : 0) | (a.bn_partial ? EPI_STATS : 0) | (a.relu_mask_in ? EPI_BITS_IN : 0) |
-                         (a.ref ? EPI_REF_IN : 0) | (a.relu_mask_out ? EPI_MASK_OUT : 0);
-        switch (kind) {
-        case EPI_PLAIN: return launch_conv_x6s_epi<G, PL, EPI_PLAIN>(a, ntiles, st);
-        case EPI_RELU: return launch_conv_x6s_epi<G, PL, EPI_RELU>(a, ntiles, st);
-        case EPI_RELU | EPI_MASK_OUT: return launch_conv_x6s_epi<G, PL, EPI_RELU | EPI_MASK_OUT>(a, ntiles, st);
-        case EPI_STATS: return launch_conv_x6s_epi<G, PL, EPI_STATS>(a, ntiles, st);
-        case EPI_BITS_IN: return launch_conv_x6s_epi<G, PL, EPI_BITS_IN>(a, ntiles, st);
-        case EPI_REF_IN: return launch_conv_x6s_epi<G, PL, EPI_REF_IN>(a, ntiles, st);
-        default: break;
-        }
+        const long long n = ntiles;
+        if (a.ref && !a.relu && !a.bn_partial && !a.relu_mask_in && !a.relu_mask_out)
+            return launch_conv_x6s_epi<G, PL, EPI_REF_IN>(a, n, st);
+        MMLF_CONV_KIND_SWITCH(launch_conv_x6s_epi, G == 18, G, PL);
     }
+    // (other widths: the generic build, whose mask words have conv_epilogue16's layout for producer and consumer alike)
     return launch_conv_x6s_epi<G, PL, EPI_GENERIC>(a, ntiles, st);
 }
 

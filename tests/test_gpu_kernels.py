@@ -724,3 +724,61 @@ def test_batched_filter_packing_and_slack_zeroing_equal_the_per_layer_calls():
     for x, y in zip(a + am, b + bm):
         assert torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0))
     assert all(float(m.abs().sum()) == 0 for m in am)
+
+
+@pytest.mark.parametrize('cin,cout', [(70, 70), (280, 280), (27, 70)])
+def test_transposed_epilogue_writes_the_same_bits(tmp_path, cin, cout):
+    """Round 5: the launch kinds plain / ReLU / ReLU + mask-out / mask-in run with TRANSPOSED accumulator tiles (weights as
+    the matrix instruction's A operand): a lane holds four consecutive channels of one position and stores 16 bytes at a
+    time (csrc/conv.hip conv_epilogue16_tr).  The values are formed by the same operations as in the other orientation, so
+    every stored byte, every row maximum and the NUMBER of ReLU bits must be identical with MMLF_CONV_TR=0 and =1 (the
+    mask words themselves have another layout); the masked data gradient -- which reads those words -- as well.  Also
+    against a channel slice at an odd offset, which the transposed form must decline (8-byte aligned rows)."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from mmlf_amd import engine, _lib
+dev = torch.device('cuda:0')
+cin, cout = int(sys.argv[2]), int(sys.argv[3])
+B, H, W = 3, 19, 45
+geo = engine.Geometry(B, H, W)
+rs = np.random.RandomState(11)
+cs_in, cs = engine.cs_of(cin), engine.cs_of(cout)
+x = geo.buf(cs_in, dev)
+v = x[:geo.NQ * cs_in].view(B, geo.R, geo.P, cs_in)
+v[:, 1:H + 1, 1:W + 1, :cin] = torch.from_numpy(rs.standard_normal((B, H, W, cin)).astype(np.float32) * np.exp(rs.uniform(-4, 4, (B, H, 1, 1))).astype(np.float32)).to(dev)
+x.absmax = geo.amax_of(x, cs_in)
+w1 = torch.from_numpy(rs.uniform(-0.3, 0.3, (cout, cin, 2, 2)).astype(np.float32)).to(dev)
+w2 = torch.from_numpy(rs.uniform(-0.3, 0.3, (cout, cout, 2, 2)).astype(np.float32)).to(dev)
+b = torch.from_numpy(rs.uniform(-0.5, 0.5, (cout,)).astype(np.float32)).to(dev)
+y, mask = geo.buf(cs, dev), torch.zeros_like(geo.relu_mask(dev))
+engine.conv(geo, x, cs_in, cin, engine.pack_filter(w1, 0, False), b, cout, y, cs, 0, H + 1, W + 1, True, mask_out=mask)   # ReLU + mask-out
+y2 = geo.buf(cs, dev)
+engine.conv(geo, x, cs_in, cin, engine.pack_filter(w1, 0, False), b, cout, y2, cs, 0, H + 1, W + 1, True)                 # ReLU
+z = geo.buf(cs, dev)
+engine.conv(geo, y, cs, cout, engine.pack_filter(w2, 0, False), b, cout, z, cs, geo.P + 1, H, W, False)                   # plain, pad 0
+g = geo.buf(cs, dev)
+engine.conv(geo, z, cs, cout, engine.pack_filter(w2, 0, True), None, cout, g, cs, 0, H + 1, W + 1, False, mask_in=mask)   # mask-in
+# a channel slice of a wider buffer at an offset that is not a multiple of four floats (evaluation: the streams' folded
+# last convolution writes [70 s, 70 s + 70) of the concat buffer): must take the other form, whatever the switch says
+wide = geo.buf(4 * cs, dev)
+engine.conv(geo, y, cs, cout, engine.pack_filter(w2, 0, False), b, cout, wide, 4 * cs, geo.P + 1, H, W, True, n_store=cout, out_off=cout + 2)
+torch.cuda.synchronize()
+np.savez(sys.argv[1], y=y.cpu().numpy(), y2=y2.cpu().numpy(), z=z.cpu().numpy(), g=g.cpu().numpy(), wide=wide.cpu().numpy(),
+         bits=np.unpackbits(mask.cpu().numpy().view(np.uint8)).sum(), ay=geo.amax_canonical(y.absmax).cpu().numpy(),
+         az=geo.amax_canonical(z.absmax).cpu().numpy(), ag=geo.amax_canonical(g.absmax).cpu().numpy())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tr in ('0', '1'):
+        out = str(tmp_path / f'tr{tr}.npz')
+        res = subprocess.run([sys.executable, '-c', script, out, str(cin), str(cout)], env=dict(os.environ, MMLF_CONV_TR=tr),
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert int(a['bits']) == int(b['bits']) == int((a['y'] > 0).sum())
+    for key in ('y', 'y2', 'z', 'g', 'wide', 'ay', 'az', 'ag'):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(a['y'], a['y2'])
