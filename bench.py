@@ -33,11 +33,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 / f16 MFMA; the split kernels spend 3 (f16x3) or 6 (bf16x6) passes per f32 product
 # the committed rocprofv3 PMC passes `roofline.traffic` is read from (tools/profile_round.sh writes it; ONE file, named in
 # the line as `traffic_source`: an older round's numbers are never substituted silently)
-PMC_SUMMARY = os.environ.get('MMLF_PMC_SUMMARY', os.path.join('profiles', 'r04c_pmc_bs512_base_summary.json'))
+PMC_SUMMARY = os.environ.get('MMLF_PMC_SUMMARY', os.path.join('profiles', 'r05_pmc_bs512_base_summary.json'))
 KW_EXTRA = {'base': {}, 'upr': {'model_uncert': True}, 'dpp': {'model_discrete': True}}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, min_ns=3e6, max_ns=1e12):
     """(HBM bytes per launch of `kernel`, source file) -- `kernel` is a name prefix: the epilogue variants of one kernel
     template are averaged, weighted by their launch counts -- from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     WRITE_SIZE runs of this same command, tools/profile_round.sh; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE, KB ->
@@ -47,7 +47,7 @@ def pmc_traffic(kernel):
     try:
         with open(path) as f:
             d = json.load(f)
-        hit = [v for k, v in d.items() if kernel in k and v.get('avg_ns', 0) > 3e6]     # the 280-wide launches
+        hit = [v for k, v in d.items() if kernel in k and min_ns < v.get('avg_ns', 0) < max_ns]     # (default: the 280-wide launches)
         if hit:
             n = sum(v['launches'] for v in hit)
             return round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit) / n), PMC_SUMMARY
@@ -242,7 +242,7 @@ def main():
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world)
 
-    from mmlf_amd import engine
+    from mmlf_amd import engine, _lib
 
     assert args.global_batch % world == 0
     B = args.global_batch // world
@@ -289,8 +289,8 @@ def main():
             p1, engine.PROFILE = engine.PROFILE, None
             engine.CONV_MODE = mode
             p1 = [r for r in p1 if r[0] == 'conv']
-            s1 = sum(e0.elapsed_time(e1) for _, _, e0, e1 in p1) * 1e-3
-            a1 = sum(f for _, f, _, _ in p1) / s1 / 1e12 if s1 > 0 else 0.0
+            s1 = sum(r[2].elapsed_time(r[3]) for r in p1) * 1e-3
+            a1 = sum(r[1] for r in p1) / s1 / 1e12 if s1 > 0 else 0.0
             pk = PEAK_F32_MFMA_TFLOPS if mode_name == 'f32' else PEAK_BF16_MFMA_TFLOPS / 6
             mode_legs[mode_name] = {
                 'value': round(args.global_batch * nsteps / dt1, 3), 'unit': 'patches/s', 'steps': nsteps,
@@ -300,9 +300,11 @@ def main():
                 'achieved': round(a1, 2), 'peak': round(pk, 1), 'frac': round(a1 / pk, 4),
                 'launches': len(p1), 'avg_ms': round(1e3 * s1 / max(1, len(p1)), 3)}
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmin = tmax.clone()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)       # a slow rank shows as max well above min
+    dt, dt_min = float(tmax), float(tmin)
     loss_val = float(loss)
 
     n_buckets = len(step.buckets.ranges) if step.buckets is not None else 0
@@ -334,9 +336,11 @@ def main():
     if rank == 0:
         value = args.global_batch * args.steps / dt
         wprof = [r for r in prof if r[0].startswith('wgrad')]
+        nprof = [r for r in prof if r[0] == 'conv70']
         prof = [r for r in prof if r[0] == 'conv']
-        secs = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof) * 1e-3
-        flops = sum(f for _, f, _, _ in prof)
+        secs = sum(r[2].elapsed_time(r[3]) for r in prof) * 1e-3
+        flops = sum(r[1] for r in prof)
+        alg_bytes = round(sum(r[4] for r in prof) / max(1, len(prof)))      # true in + out of a launch, mean over the launches
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
         passes = {'f16x3': 3, 'bf16x6': 6}.get(engine.CONV_MODE)
         split = passes is not None
@@ -364,15 +368,36 @@ def main():
                          'peak_is': (f'dense 16-bit MFMA 2500 TFLOP/s / {passes} passes per f32 product' if split
                                      else 'f32 MFMA 157.3 TFLOP/s'),
                          'frac_of_f32_mfma_peak': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         'algorithmic_bytes': round(2.0 * B * 98 * 98 * 280 * 4) if args.patch == 96 else None,
+                         'algorithmic_bytes': alg_bytes,
+                         'traffic_ratio': round(traffic[0] / alg_bytes, 3) if traffic[0] and alg_bytes else None,
                          'launches': len(prof), 'avg_ms': round(1e3 * secs / max(1, len(prof)), 3)},
         }
+        line['config']['build'] = _lib.build_info()
+        line['config']['conv_cus'] = int(_lib.load().mmlf_conv_cus())
+        if nprof:      # the kernel furthest from its roof: the 70 -> 70 stream-layer convolutions, HBM-bound (70 FLOP/B < ridge)
+            nsecs = sum(r[2].elapsed_time(r[3]) for r in nprof) * 1e-3
+            nbytes = sum(r[4] for r in nprof)
+            nflops = sum(r[1] for r in nprof)
+            ntraffic = (pmc_traffic('conv4tap_x6s_kernel<5, 2', 5e5, 3e6) if args.global_batch == 512 and world == 1
+                        else (None, 'n/a: not the bs=512 single-GPU shape'))
+            nalg = round(nbytes / len(nprof))
+            line['roofline_narrow'] = {
+                'bound': 'hbm', 'achieved': round(nbytes / nsecs / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                'frac': round(nbytes / nsecs / 1e9 / 8000.0, 4),
+                'peak_is': 'HBM3E spec 8 TB/s (MI355X_MICROARCH.md); 6.29 TB/s is the best streaming rate measured on this part',
+                'frac_of_measured_hbm': round(nbytes / nsecs / 1e9 / 6290.0, 4),
+                'kernel': 'conv4tap_x6s_kernel<5, 2, EPI, 16> (70->70 forward + data-gradient launches of the four stream nets)',
+                'traffic': ntraffic[0], 'traffic_source': ntraffic[1], 'algorithmic_bytes': nalg,
+                'traffic_ratio': round(ntraffic[0] / nalg, 3) if ntraffic[0] else None,
+                'mfma_tflops': round(nflops / nsecs / 1e12, 1), 'launches': len(nprof),
+                'avg_ms': round(1e3 * nsecs / len(nprof), 3)}
         if wprof:      # the 280-wide weight gradient: the largest single kernel of the step, same peak definition
-            wsecs = sum(e0.elapsed_time(e1) for _, _, e0, e1 in wprof) * 1e-3
-            wach = sum(f for _, f, _, _ in wprof) / wsecs / 1e12
+            wsecs = sum(r[2].elapsed_time(r[3]) for r in wprof) * 1e-3
+            wach = sum(r[1] for r in wprof) / wsecs / 1e12
+            walg = round(sum(r[4] for r in wprof) / len(wprof))
             side = [r for r in wprof if r[0] == 'wgrad_side']
             main = [r for r in wprof if r[0] == 'wgrad']
-            avg = lambda rs: round(sum(e0.elapsed_time(e1) for _, _, e0, e1 in rs) / len(rs), 3) if rs else None
+            avg = lambda rs: round(sum(r[2].elapsed_time(r[3]) for r in rs) / len(rs), 3) if rs else None
             wname = f'wgrad4tap_x6w_kernel<3, 9, {2 if passes == 3 else 3}>' if split else 'wgrad4tap_kernel<9>'
             wtraffic = (pmc_traffic(wname.split('<')[0]) if args.global_batch == 512 and world == 1
                         else (None, 'n/a: not the bs=512 single-GPU shape'))
@@ -384,9 +409,11 @@ def main():
                                      'BatchNorm-backward kernels)' if engine.OVERLAP_WGRAD else ')'),
                 'launches': len(wprof), 'avg_ms': round(1e3 * wsecs / len(wprof), 3),
                 'avg_ms_main_stream': avg(main), 'avg_ms_side_stream': avg(side),
-                'algorithmic_bytes': round(2.0 * B * 98 * 98 * 280 * 4) if args.patch == 96 else None}
+                'algorithmic_bytes': walg, 'traffic_ratio': round(wtraffic[0] / walg, 3) if wtraffic[0] else None}
         if world > 1:
+            line['ms_per_step_by_rank'] = {'min': round(1e3 * dt_min / args.steps, 3), 'max': round(1e3 * dt / args.steps, 3)}
             line['config']['buckets'] = n_buckets
+            line['config']['buckets_env'] = os.environ.get('MMLF_GRAD_BUCKETS')
             line['config']['gradient_bytes'] = grad_bytes
             if ese_rep is not None:
                 line['ese_replicas'] = ese_rep
@@ -399,6 +426,10 @@ def main():
             line['exact_f32_mfma_path'] = mode_legs['f32']
         if 'bf16x6' in mode_legs:
             line['bf16x6_path'] = mode_legs['bf16x6']
+        if mode_legs:      # the same step in the arithmetic modes that are no narrower than the reference's fp32, beside `value`
+            line['strict_precision'] = dict({k: v['value'] for k, v in mode_legs.items()}, unit='patches/s',
+                                            note='bf16x6 = exact 3 x bf16 operand split, f32 = exact-f32 MFMA; `value` above is the '
+                                                 'f16x3 mode (22 significant bits per operand, float32-level error measured)')
         if world == 1 and not args.no_extra_legs and args.global_batch == 512 and args.patch == 96:
             # the other BASELINE.json configs, driver-timed in the same run (single GPU each)
             del step, stacks, gt, mask

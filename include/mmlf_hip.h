@@ -258,6 +258,14 @@ int mmlf_head_upr(const float *output_nchw, const float *grid108, float *posteri
 int mmlf_head_dpp(const float *scores_nchw, const float *grid_torch, const float *grid_np,
                   float *one_hot, float *posterior, float *mean, float *logvar, int steps,
                   int B, int H, int W, void *stream);
+/* Backward of the heads: gradients of `posterior` (UPR) and of `posterior` / `logvar` (DPP) with respect to the network
+ * output, for callers that put a loss on them (the reference's graph has these edges, feed_forward.py:276-302; its own
+ * losses do not use them).  grad_output (B,2,H,W) / grad_scores (B,steps,H,W) are WRITTEN.  DPP: `mean` is the forward's
+ * arg-max depth (a constant of the graph, as in the reference); grad_posterior or grad_logvar may be null. */
+int mmlf_head_upr_bwd(const float *output_nchw, const float *grid108, const float *grad_posterior, float *grad_output,
+                      int steps, int B, int H, int W, void *stream);
+int mmlf_head_dpp_bwd(const float *scores_nchw, const float *grid_np, const float *mean, const float *grad_posterior,
+                      const float *grad_logvar, float *grad_scores, int steps, int B, int H, int W, void *stream);
 
 /* Losses (value + gradient w.r.t. the raw out_net output, NCHW), reference mmlf/model/loss.py.
  * kind 0: MaskedL1Loss (:70-77)  1: ImprovedUncertaintyL1Loss without mask_padding (:264-294)

@@ -65,6 +65,8 @@ SIGNATURES = {
     'mmlf_unpack_nchw': (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_head_upr': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_head_dpp': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_head_upr_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_head_dpp_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mmlf_loss_fwd_bwd': (_i, [_i, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     'mmlf_loss_multi_scratch_doubles': (_i64, [_i]),
     'mmlf_loss_multi_fwd_bwd': (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),

@@ -1834,7 +1834,8 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     // items of a piece are all surplus (3 of 8 on the second activation piece, 4 of 8 on the fifth gradient piece at <3, 9>)
     // skip the piece -- less work, no 64 lanes storing to one LDS address -- and the launch took 8.53 ms instead of 8.17
     // (profiles/r05_kbench_wgrad_surplus.log): a branch per column block ends the basic block the MFMAs and the staging
-    // instructions are interleaved in.
+    // instructions are interleaved in.  Nor do the surplus lanes' stores to ONE address cost anything: giving every such lane
+    // an LDS slot of its own measured 8.04 ms against 8.02 (profiles/r05_kbench_wgrad_surplus.log) -- equal addresses merge.
 #define WW_GLOAD_A(j, c)                                                                                    \
     do {                                                                                                    \
         const long long Qc = (long long)(c) * WG_KQ;                                                        \

@@ -482,6 +482,66 @@ __global__ void head_dpp_kernel(const float *__restrict__ sc, const float *__res
     }
 }
 
+// Backward of the two heads (round 5): the reference builds `posterior` (UPR, DPP) and the DPP `logvar` as differentiable
+// functions of the network output (feed_forward.py:276-302); no reference loss uses them (loss.py:70,146,264), but a
+// drop-in module must not silently cut a graph the reference has.
+//  UPR: post_k = exp(-|g_k - mu| / b) / (2 b), b = exp(lv):  d post_k / d mu = post_k sign(g_k - mu) / b,
+//       d post_k / d lv = post_k (|g_k - mu| / b - 1).
+//  DPP: p = exp(s) / sum exp(s), lv = log V, V = sum_k (g_k - m)^2 p_k with m (from the one-hot arg-max) a constant:
+//       dL/dp_k = go_post_k + go_lv (g_k - m)^2 / V,  dL/ds_i = p_i (dL/dp_i - sum_j dL/dp_j p_j).
+__global__ void head_upr_bwd_kernel(const float *__restrict__ out, const float *__restrict__ grid,
+                                    const float *__restrict__ gpost, float *__restrict__ gout, int steps, int HW, long long total)
+{
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / HW;
+        const int p = (int)(idx - b * HW);
+        const float mu = out[(b * 2 + 0) * HW + p];
+        const float bb = expf(out[(b * 2 + 1) * HW + p]);
+        float gm = 0.f, gl = 0.f;
+        for (int k = 0; k < steps; ++k) {
+            const float go = gpost[(b * steps + k) * HW + p];
+            const float d = grid[k] - mu, pk = laplace_pdf(grid[k], mu, bb);
+            gm = fmaf(go * pk, (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / bb, gm);     // torch: d|x|/dx = sign(x), 0 at 0
+            gl = fmaf(go * pk, fabsf(d) / bb - 1.f, gl);
+        }
+        gout[(b * 2 + 0) * HW + p] = gm;
+        gout[(b * 2 + 1) * HW + p] = gl;
+    }
+}
+
+__global__ void head_dpp_bwd_kernel(const float *__restrict__ sc, const float *__restrict__ gn, const float *__restrict__ mean,
+                                    const float *__restrict__ gpost, const float *__restrict__ glv,
+                                    float *__restrict__ gsc, int steps, int HW, long long total)
+{
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / HW;
+        const int p = (int)(idx - b * HW);
+        const float *s = sc + b * steps * HW + p;
+        const float m = mean[idx];
+        float z = 0.f;
+        for (int k = 0; k < steps; ++k) z += expf(s[(size_t)k * HW]);
+        float V = 0.f;
+        for (int k = 0; k < steps; ++k) {
+            const float d = gn[k] - m;
+            V = fmaf(d * d, expf(s[(size_t)k * HW]) / z, V);
+        }
+        const float gl = glv ? glv[idx] / V : 0.f;
+        float dot = 0.f;                       // sum_j dL/dp_j p_j
+        for (int k = 0; k < steps; ++k) {
+            const float d = gn[k] - m, pk = expf(s[(size_t)k * HW]) / z;
+            const float dp = (gpost ? gpost[(b * steps + k) * HW + p] : 0.f) + gl * d * d;
+            dot = fmaf(dp, pk, dot);
+        }
+        for (int k = 0; k < steps; ++k) {
+            const float d = gn[k] - m, pk = expf(s[(size_t)k * HW]) / z;
+            const float dp = (gpost ? gpost[(b * steps + k) * HW + p] : 0.f) + gl * d * d;
+            gsc[(b * steps + k) * HW + p] = pk * (dp - dot);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // losses: pass 1 partial (count, sum), finalize, pass 2 gradient
 // ---------------------------------------------------------------------------------------------
@@ -1314,6 +1374,27 @@ extern "C" int mmlf_head_dpp(const float *scores, const float *grid_torch, const
     hipLaunchKernelGGL(head_dpp_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, scores, grid_torch,
                        grid_np, one_hot, posterior, mean, logvar, steps, H * W, total);
     return mmlf_launch_status("mmlf_head_dpp");
+}
+
+extern "C" int mmlf_head_upr_bwd(const float *output, const float *grid108, const float *grad_posterior, float *grad_output,
+                                 int steps, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(output && grid108 && grad_posterior && grad_output && steps > 0, "mmlf_head_upr_bwd: bad argument");
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(head_upr_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, output, grid108,
+                       grad_posterior, grad_output, steps, H * W, total);
+    return mmlf_launch_status("mmlf_head_upr_bwd");
+}
+
+extern "C" int mmlf_head_dpp_bwd(const float *scores, const float *grid_np, const float *mean, const float *grad_posterior,
+                                 const float *grad_logvar, float *grad_scores, int steps, int B, int H, int W, void *stream)
+{
+    MMLF_CHECK_ARG(scores && grid_np && mean && grad_scores && steps > 0 && (grad_posterior || grad_logvar),
+                   "mmlf_head_dpp_bwd: bad argument");
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(head_dpp_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, scores, grid_np, mean,
+                       grad_posterior, grad_logvar, grad_scores, steps, H * W, total);
+    return mmlf_launch_status("mmlf_head_dpp_bwd");
 }
 
 extern "C" int mmlf_loss_fwd_bwd(int kind, const float *output, int oc, const float *gt, const int32_t *mask,

@@ -161,8 +161,11 @@ class _Workspace:
         return {key: v for (key, _, _, _), v in zip(items, views)}
 
     def enter_stream(self):
-        """Called where a workspace-owned buffer is about to be overwritten: if the calling thread has moved to another
-        stream since this workspace was last used, that stream waits for the work the previous one had enqueued."""
+        """Orders a change of stream for EVERY buffer this workspace owns (the packed-filter store, `partial`, the
+        scratch and weight-gradient buffers): if the calling thread has moved to another stream since the workspace was
+        last used, the new stream first waits for the work the previous one had enqueued.  Called from the places that hand
+        out or overwrite those buffers -- packed_filters(), scratch(), wgrad_ws() -- and at the entry of Trunk.forward /
+        Trunk.backward (which use `partial` directly); one comparison per call when the stream has not changed."""
         if self.device.type != 'cuda':
             return
         cur = torch.cuda.current_stream(self.device)
@@ -173,6 +176,8 @@ class _Workspace:
 
     def scratch(self, name, n):
         """a float32 scratch buffer of at least n elements, reused across calls of this thread on this stream"""
+        if not name.endswith('_side'):      # (side-stream launches are ordered by their own events, _block_bwd)
+            self.enter_stream()
         t = getattr(self, name, None)
         if t is None or t.numel() < n:
             t = torch.empty(n, dtype=torch.float32, device=self.device)
@@ -184,6 +189,8 @@ class _Workspace:
         if n < 0:
             raise RuntimeError(f'wgrad: unsupported channels {cin}->{cout}')
         name = 'wgrad_side' if side else 'wgrad'
+        if not side:                 # (the side stream's launches are ordered by their own events, _block_bwd)
+            self.enter_stream()
         if getattr(self, name) is None or getattr(self, name).numel() < n:
             setattr(self, name, torch.empty(n, dtype=torch.float32, device=self.device))
         return getattr(self, name)
@@ -282,7 +289,8 @@ def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace
         # algorithmic FLOPs: the convolution's valid output positions x Cout x 4 taps x Cin, 2 FLOP per MAC (the
         # gradient of a pad-1 convolution lives at grid offset 0 with extent (H+1, W+1), of a pad-0 one at (1, 1))
         vh, vw = (geo.H + 1, geo.W + 1) if g_shift == 0 else (geo.H, geo.W)
-        PROFILE.append(('wgrad_side' if side else 'wgrad', 2.0 * geo.B * vh * vw * cout * 4 * cin, e0, e1))
+        nbytes = 4.0 * geo.B * (cin * (geo.H * geo.W if g_shift == 0 else (geo.H + 1) * (geo.W + 1)) + cout * vh * vw)
+        PROFILE.append(('wgrad_side' if side else 'wgrad', 2.0 * geo.B * vh * vw * cout * 4 * cin, e0, e1, nbytes))
 
 
 def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu, ref=None, cs_ref=0,
@@ -298,7 +306,8 @@ def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu
         call('mmlf_conv2x2_thin', ptr(x), cs_in, K, ptr(w_master), ptr(bias), N, ptr(out), cs_out, out_shift, vh, vw,
              geo.B, geo.H, geo.W, int(relu), variant, ptr(ws), ptr(getattr(out, 'absmax', None)), _lib.stream_ptr())
         return
-    prof = PROFILE is not None and K >= 256 and N >= 256
+    # bench.py's per-launch timing: the 280-wide launches (tag 'conv') and the 70 -> 70 stream-layer launches ('conv70')
+    prof = PROFILE is not None and ((K >= 256 and N >= 256) or (K == N and 64 <= K < 128))
     if prof:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -312,8 +321,11 @@ def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu
         call('mmlf_conv2x2_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2', *args, _lib.stream_ptr())
     if prof:
         e1.record()
-        # algorithmic FLOPs of this launch: valid output positions x N x 4 taps x K, 2 FLOP per MAC
-        PROFILE.append(('conv', 2.0 * geo.B * vh * vw * N * 4 * K, e0, e1))
+        # algorithmic FLOPs of this launch: valid output positions x N x 4 taps x K, 2 FLOP per MAC; algorithmic BYTES: the
+        # input's and the output's stored extents once each (a pad-1 convolution reads (H, W) and writes (H+1, W+1), a pad-0
+        # one the other way round), float32, unpadded channels
+        nbytes = 4.0 * geo.B * (K * (geo.H * geo.W if out_shift == 0 else (geo.H + 1) * (geo.W + 1)) + N * vh * vw)
+        PROFILE.append(('conv' if K >= 256 else 'conv70', 2.0 * geo.B * vh * vw * N * 4 * K, e0, e1, nbytes))
 
 
 class BlockSpec:
@@ -468,6 +480,7 @@ class Trunk:
         dev = h.device
         geo = Geometry(B, H, W)
         cin0 = n * c
+        _Workspace.get(dev).enter_stream()
         packs = self._prepack(p, dev, save)
         tracked = []                  # BatchNorm counters of this pass: ONE increment launch at its end
         tape = {'geo': geo, 'streams': [], 'out': [], 'packs': packs}
@@ -592,6 +605,7 @@ class Trunk:
         'in_net_id' / 'in_net_hv' has been enqueued (gradient-bucket all-reduce hook)."""
         geo = tape['geo']
         dev = grad_output.device
+        _Workspace.get(dev).enter_stream()
         B, H, W = geo.B, geo.H, geo.W
         cs = cs_of(self.oc)
         g = geo.buf(cs, dev)

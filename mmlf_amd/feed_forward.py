@@ -118,6 +118,64 @@ class _TrunkFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None) + tuple(grads[n] for n in names)
 
 
+class _HeadUprFn(torch.autograd.Function):
+    """posterior of the UPR head (reference feed_forward.py:292-302) as a differentiable function of the network output:
+    forward = mmlf_head_upr, backward = mmlf_head_upr_bwd (round 5: the native path used to compute it from a detached
+    tensor, so a loss on output['posterior'] trained nothing on cuda while it did on the stock-torch branch)."""
+
+    @staticmethod
+    def forward(ctx, output, grid, steps):
+        o = output.detach().contiguous()
+        b, _, hh, ww = o.shape
+        posterior = torch.empty((b, steps, hh, ww), dtype=torch.float32, device=o.device)
+        call('mmlf_head_upr', ptr(o), ptr(grid), ptr(posterior), steps, b, hh, ww, _lib.stream_ptr())
+        ctx.save_for_backward(o, grid)
+        ctx.steps = steps
+        return posterior
+
+    @staticmethod
+    def backward(ctx, gpost):
+        o, grid = ctx.saved_tensors
+        b, _, hh, ww = o.shape
+        gout = torch.empty_like(o)
+        with torch.cuda.device(o.device):
+            call('mmlf_head_upr_bwd', ptr(o), ptr(grid), ptr(gpost.contiguous()), ptr(gout), ctx.steps, b, hh, ww,
+                 _lib.stream_ptr())
+        return gout, None, None
+
+
+class _HeadDppFn(torch.autograd.Function):
+    """one_hot, posterior, mean, logvar of the DPP head (reference feed_forward.py:276-290): posterior and logvar are
+    differentiable in the scores (mmlf_head_dpp_bwd); one_hot and the arg-max mean are constants of the graph, as in the
+    reference (a comparison has no gradient)."""
+
+    @staticmethod
+    def forward(ctx, scores, grid_torch, grid_np, steps):
+        sc = scores.detach().contiguous()
+        b, _, hh, ww = sc.shape
+        one_hot, posterior = torch.empty_like(sc), torch.empty_like(sc)
+        mean = torch.empty((b, hh, ww), dtype=torch.float32, device=sc.device)
+        logvar = torch.empty_like(mean)
+        call('mmlf_head_dpp', ptr(sc), ptr(grid_torch), ptr(grid_np), ptr(one_hot), ptr(posterior), ptr(mean), ptr(logvar),
+             steps, b, hh, ww, _lib.stream_ptr())
+        ctx.save_for_backward(sc, grid_np, mean)
+        ctx.steps = steps
+        ctx.mark_non_differentiable(one_hot, mean)
+        return one_hot, posterior, mean, logvar
+
+    @staticmethod
+    def backward(ctx, g_one_hot, g_post, g_mean, g_lv):
+        sc, grid_np, mean = ctx.saved_tensors
+        if g_post is None and g_lv is None:
+            return None, None, None, None
+        b, _, hh, ww = sc.shape
+        gsc = torch.empty_like(sc)
+        with torch.cuda.device(sc.device):
+            call('mmlf_head_dpp_bwd', ptr(sc), ptr(grid_np), ptr(mean), ptr(None if g_post is None else g_post.contiguous()),
+                 ptr(None if g_lv is None else g_lv.contiguous()), ptr(gsc), ctx.steps, b, hh, ww, _lib.stream_ptr())
+        return gsc, None, None, None
+
+
 class FeedForward(nn.Module):
     def __init__(self, model_ksize, model_in_blocks, model_out_blocks, model_chs, model_views,
                  model_cross, model_uncert, model_unet, model_discrete, model_no_batchnorm,
@@ -237,13 +295,9 @@ class FeedForward(nn.Module):
         if self.discrete:
             scores = output
             if native:
-                sc = scores.detach().contiguous()
-                one_hot = torch.empty_like(sc)
-                posterior = torch.empty_like(sc)
-                mean = torch.empty((b, hh, ww), dtype=torch.float32, device=sc.device)
-                logvar = torch.empty_like(mean)
-                call('mmlf_head_dpp', ptr(sc), ptr(self._grid('torch', sc.device)), ptr(self._grid('np', sc.device)),
-                     ptr(one_hot), ptr(posterior), ptr(mean), ptr(logvar), self.steps, b, hh, ww, _lib.stream_ptr())
+                with torch.cuda.device(scores.device):
+                    one_hot, posterior, mean, logvar = _HeadDppFn.apply(scores, self._grid('torch', scores.device),
+                                                                        self._grid('np', scores.device), self.steps)
             else:
                 one_hot = (torch.max(scores, 1, keepdim=True)[0] == scores).float()
                 e = torch.exp(scores)
@@ -254,10 +308,8 @@ class FeedForward(nn.Module):
         if self.uncert:
             logvar = output[:, 1]
             if native:
-                o = output.detach().contiguous()
-                posterior = torch.empty((b, self.steps, hh, ww), dtype=torch.float32, device=o.device)
-                call('mmlf_head_upr', ptr(o), ptr(self._grid('np', o.device)), ptr(posterior), self.steps,
-                     b, hh, ww, _lib.stream_ptr())
+                with torch.cuda.device(output.device):
+                    posterior = _HeadUprFn.apply(output, self._grid('np', output.device), self.steps)
             else:
                 g = self._grid('np', output.device).view(1, -1, 1, 1).expand(b, self.steps, hh, ww)
                 posterior = laplacian(g, mean, torch.exp(logvar))

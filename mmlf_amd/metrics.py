@@ -120,8 +120,9 @@ def nll_discrete(weights, posterior, vmin=None, vmax=None, mask=None, inplace=Fa
         weights.div_(weights.sum(1, keepdim=True))
         posterior.div_(posterior.sum(1, keepdim=True) * 7.0)
     else:
-        weights = _f64(weights) + eps
-        posterior = posterior + eps                      # the reference keeps the model's float32 here
+        weights = weights + eps                          # the array's own dtype in BOTH branches, as the reference's numpy
+        posterior = posterior + eps                      # helper works (validate/cli.py:52-73): the two modes then differ
+                                                         # by the in-place smoothing alone, as the docstring says
         weights = weights / weights.sum(1, keepdim=True)
         posterior = posterior / (posterior.sum(1, keepdim=True) * 7.0)
     nllh = (weights * -torch.log(posterior)).sum(1)

@@ -86,31 +86,72 @@ def validation_pass(val_model, batches, uncert=False, loss_multimodal=False, mar
     return loss_val_avg / n, mse_avg / n, bad_pix_avg / n
 
 
-class GradBuckets:
-    """Contiguous slices of the flat gradient, one per out_net block / stream net, all-reduced as
-    soon as the backward pass has finished the layers they cover."""
+def bucket_count(default=10):
+    """MMLF_GRAD_BUCKETS=<n>: how many all-reduces carry the gradient of a step (1 ... 10; default: one per out_net block
+    and stream net).  Fewer, larger messages cost less launch / protocol overhead per byte on point-to-point xGMI links and
+    give the collective's kernels fewer chances to queue behind a running 7 ms persistent convolution; more of them start
+    earlier under backward.  The first multi-GPU run decides; bench.py reports the value in config.buckets."""
+    import os
+    try:
+        n = int(os.environ.get('MMLF_GRAD_BUCKETS', default))
+    except ValueError:
+        n = default
+    return max(1, n)
 
-    def __init__(self, layout, group=None):
+
+class GradBuckets:
+    """Contiguous slices of the flat gradient, all-reduced as soon as the backward pass has finished the layers they
+    cover.  The finest division is one slice per out_net block / stream net (`keys`, in the order backward completes them:
+    out_net.7 ... out_net.0, in_net_id, in_net_hv -- the reverse of their order in the flat buffer, so any run of
+    consecutive keys is one contiguous range); `n_buckets` < len(keys) coalesces runs of consecutive keys into one
+    all-reduce each, issued when the LAST key of the run is ready."""
+
+    def __init__(self, layout, group=None, n_buckets=None):
         self.group = group
-        self.ranges = {}
+        fine = {}
         for name, o, n in layout:
             key = name.split('.')[0] if name.startswith('in_net') else '.'.join(name.split('.')[:2])
-            lo, hi = self.ranges.get(key, (o, o + n))
-            self.ranges[key] = (min(lo, o), max(hi, o + n))
+            lo, hi = fine.get(key, (o, o + n))
+            fine[key] = (min(lo, o), max(hi, o + n))
+        # completion order of backward = descending offset in the flat buffer
+        self.keys = sorted(fine, key=lambda k: -fine[k][0])
+        n_buckets = bucket_count(len(self.keys)) if n_buckets is None else int(n_buckets)
+        n_buckets = max(1, min(n_buckets, len(self.keys)))
+        # runs of consecutive keys, as even in count as possible (the wide blocks are equal in bytes; the two stream nets
+        # together are 5 % of the gradient and share the last run's tail)
+        bounds = [round(i * len(self.keys) / n_buckets) for i in range(n_buckets + 1)]
+        self.ranges, self.trigger, self.bucket_of = {}, {}, {}
+        for b in range(n_buckets):
+            run = self.keys[bounds[b]:bounds[b + 1]]
+            lo, hi = min(fine[k][0] for k in run), max(fine[k][1] for k in run)
+            assert hi - lo == sum(fine[k][1] - fine[k][0] for k in run), 'bucket keys must be contiguous in the flat gradient'
+            self.ranges[run[-1]] = (lo, hi)             # keyed by the key that completes the run
+            for k in run:
+                self.bucket_of[k] = run[-1]
         self.pending = []
         self.done = set()
+        self.seen = set()
         self.wait_events = None      # bench.py: a list that receives (start, end) HIP events around each step's waits
 
     def ready(self, flat_grad, key):
-        if key in self.done or key not in self.ranges:
+        """backward has enqueued every gradient of `key`: fire its bucket if that completes the bucket's run"""
+        if key not in self.bucket_of:
             return
-        self.done.add(key)
-        lo, hi = self.ranges[key]
+        self.seen.add(key)
+        last = self.bucket_of[key]
+        if last in self.done or key != last:
+            return
+        self._fire(flat_grad, last)
+
+    def _fire(self, flat_grad, last):
+        self.done.add(last)
+        lo, hi = self.ranges[last]
         self.pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self, flat_grad):
-        for key in self.ranges:
-            self.ready(flat_grad, key)
+        for last in self.ranges:
+            if last not in self.done:
+                self._fire(flat_grad, last)
         timed = self.wait_events is not None and flat_grad.is_cuda
         if timed:       # how long the compute stream stands behind the collectives once backward is through
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -120,7 +161,7 @@ class GradBuckets:
         if timed:
             e1.record()
             self.wait_events.append((e0, e1))
-        self.pending, self.done = [], set()
+        self.pending, self.done, self.seen = [], set(), set()
 
 
 class TrainStep:

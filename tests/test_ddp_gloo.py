@@ -57,8 +57,12 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_n_rank_step_equals_manual_average(tmp_path, world):
+@pytest.mark.parametrize('world,buckets', [(2, None), (4, None), (2, '1'), (2, '3')])
+def test_n_rank_step_equals_manual_average(tmp_path, world, buckets, monkeypatch):
+    """buckets: MMLF_GRAD_BUCKETS -- the gradient carried by one / three all-reduces instead of one per block (round 5:
+    the knob the first 8-GPU run needs); the result must not depend on it"""
+    if buckets is not None:
+        monkeypatch.setenv('MMLF_GRAD_BUCKETS', buckets)      # (inherited by the spawned ranks)
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     ranks = [torch.load(tmp_path / f'r{r}.pt') for r in range(world)]
@@ -124,6 +128,43 @@ def test_bucket_layout_covers_every_parameter_once():
         assert torch.equal(v, v2), k
     p = dict(m.named_parameters())['out_net.0.0.weight']
     assert p.data_ptr() >= flat.data_ptr() and p.data_ptr() < flat.data_ptr() + flat.numel() * 4
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 4, 5, 10])
+def test_coalesced_buckets_are_contiguous_runs_in_backward_order(n):
+    m = _make()
+    flat, layout = flatten_parameters(m)
+    b = GradBuckets(layout, n_buckets=n)
+    assert b.keys == ['out_net.2', 'out_net.1', 'out_net.0', 'in_net_id', 'in_net_hv']     # the order backward completes them
+    assert len(b.ranges) == min(n, 5)
+    spans = sorted(b.ranges.values())
+    assert spans[0][0] == 0 and spans[-1][1] == flat.numel()
+    for (_, hi), (lo, _) in zip(spans, spans[1:]):
+        assert hi == lo
+    # a bucket is keyed by the key that completes it: every key before it in backward order belongs to the same or an earlier bucket
+    for last, (lo, hi) in b.ranges.items():
+        members = [k for k in b.keys if b.bucket_of[k] == last]
+        assert members[-1] == last and members == b.keys[b.keys.index(members[0]):b.keys.index(last) + 1]
+    # firing: nothing goes out before a bucket's last key is ready, everything by finish()
+    calls = []
+    b._fire = lambda g, last: (calls.append(last), b.done.add(last))
+    for k in b.keys:
+        b.ready(flat, k)
+        assert calls == [last for last in b.ranges if b.keys.index(last) <= b.keys.index(k)]
+    assert len(calls) == len(b.ranges)
+
+
+def test_bucket_count_comes_from_the_environment(monkeypatch):
+    from mmlf_amd.train import bucket_count
+    monkeypatch.delenv('MMLF_GRAD_BUCKETS', raising=False)
+    assert bucket_count(10) == 10
+    monkeypatch.setenv('MMLF_GRAD_BUCKETS', '3')
+    assert bucket_count(10) == 3
+    m = _make()
+    _, layout = flatten_parameters(m)
+    assert len(GradBuckets(layout).ranges) == 3
+    monkeypatch.setenv('MMLF_GRAD_BUCKETS', '0')
+    assert bucket_count(10) == 1
 
 
 def test_flat_adam_matches_torch_adam():

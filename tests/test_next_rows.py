@@ -302,3 +302,19 @@ def test_validation_loop_runs_the_ensemble_on_the_gpu(tmp_path):
     assert pfm.load(str(tmp_path / 'ours' / 'disp_maps' / 's1.pfm')).shape == (24, 24)
     assert np.load(str(tmp_path / 'scenes' / 's0' / 'gmm.npy')).shape == (2, 70, 24, 24)
     assert np.load(str(tmp_path / 'scenes' / 's0' / 'posterior.npy')).shape == (70, 24, 24)
+
+
+def test_nll_discrete_modes_differ_by_the_in_place_smoothing_alone():
+    """round 4's advisor finding: the two modes of metrics.nll_discrete used different dtypes (float64 weights without
+    in-place, the array's own float32 with), so validate_scenes(reference_compat=True / False) returned NLLs that
+    differed for a reason unrelated to the documented smoothing sequence.  Both work in the array's own dtype now, as the
+    reference's numpy helper does (reference validate/cli.py:52-73): on fresh copies the two modes give the SAME number."""
+    g = torch.Generator().manual_seed(3)
+    weights = torch.rand((1, 108, 9, 11), generator=g)
+    weights /= weights.sum(1, keepdim=True)
+    post = torch.softmax(torch.randn((1, 108, 9, 11), generator=g), 1)
+    w0, p0 = weights.clone(), post.clone()
+    a = metrics.nll_discrete(weights, post, inplace=False)
+    assert torch.equal(weights, w0) and torch.equal(post, p0) and a.dtype == torch.float32
+    b = metrics.nll_discrete(weights.clone(), post.clone(), inplace=True)
+    assert torch.equal(a, b), (float(a), float(b))

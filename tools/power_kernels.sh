@@ -1,9 +1,14 @@
 #!/bin/bash
 # Socket power per launch kind: tools/kbench.py with long timed loops (KBENCH_STAMP=1 prints each loop's wall-clock window), rocm-smi
 # sampled beside it, samples averaged per window.   gpurun -- bash tools/power_kernels.sh gpurun_out/power_kernels.log [reps]
+# The environment the launches run under is part of the record (round 4's log was made with AMD_SERIALIZE_KERNEL=3 set by
+# hand, which this script did not say): the script sets it itself now -- override by exporting another value -- and writes
+# every AMD_* / HSA_* / HIP_* / MMLF_* variable in effect to $out.env, which the summary repeats in its first line.
 out=${1:-gpurun_out/power_kernels.log}
 reps=${2:-250}
 mkdir -p "$(dirname "$out")"
+export AMD_SERIALIZE_KERNEL=${AMD_SERIALIZE_KERNEL:-3}
+env | grep -E '^(AMD_|HSA_|HIP_|MMLF_|KBENCH_)' | sort > "$out.env"
 KBENCH_STAMP=1 python tools/kbench.py 512 $reps power > "$out.kbench" 2> "$out.err" &
 pid=$!
 : > "$out.smi"
@@ -21,6 +26,7 @@ for b in re.split(r'\n(?=\d{10}\.\d+)', open(out + '.smi').read()):
     if m and p and s:
         samples.append((float(m.group(1)), float(p.group(1)), int(s.group(1))))
 with open(out, 'w') as f:
+    f.write('# environment: ' + ' '.join(open(out + '.env').read().split()) + '\n')
     for line in open(out + '.kbench'):
         m = re.search(r'window (\d+\.\d+) (\d+\.\d+)', line)
         if not m:
