@@ -2512,13 +2512,17 @@ static int launch_conv_rs_epi(const ConvArgs &a, long long ngroups, hipStream_t 
     return mmlf_launch_status("mmlf_conv2x2_h2(register-streamed)");
 }
 // launch kind -> epilogue build.  tr: the transposed form, for the kinds that have one
-// (TR_PLAIN: whether the plain kind has one too -- on the 80-column kernels it measured 3 % slower: profiles/r05_kbench_tr.log)
-#define MMLF_CONV_KIND_SWITCH(LAUNCH, TR_PLAIN, ...)                                                                              \
+// (TR_PLAIN: whether the plain kind has one too -- on the 80-column kernels it measured 3 % slower: profiles/r05_kbench_tr.log;
+//  TR_SHAPE: a condition on the launch geometry -- the 288-column tiled kernel takes the transposed form on small pitches only:
+//  with two-segment activation windows (full frames, pitch > 383) its ReLU launches measured 26.7 ms against 24.3 in the other
+//  orientation, profiles/r05_ese_tr_kernel_stats.log, while at training pitches they are 0.5-2 % faster.  The condition depends
+//  on (B, H, W) and the kernel alone, so a mask's producer and its consumer always agree.)
+#define MMLF_CONV_KIND_SWITCH(LAUNCH, TR_PLAIN, TR_SHAPE, ...)                                                                              \
     do {                                                                                                                \
         const int kind = (a.relu ? EPI_RELU : 0) | (a.bn_partial ? EPI_STATS : 0) | (a.relu_mask_in ? EPI_BITS_IN : 0) | \
                          (a.ref ? EPI_REF_IN : 0) | (a.relu_mask_out ? EPI_MASK_OUT : 0);                               \
-        const bool tr = conv_tr_enabled() && conv_tr_fits(a);                                                           \
-        if ((a.relu_mask_in || a.relu_mask_out) && conv_tr_enabled() && !tr)                                            \
+        const bool tr = conv_tr_enabled() && (TR_SHAPE) && conv_tr_fits(a);                                             \
+        if ((a.relu_mask_in || a.relu_mask_out) && conv_tr_enabled() && (TR_SHAPE) && !tr)                              \
             return mmlf_fail("mmlf_conv2x2_h2: ReLU mask words need n_store %% 4 == 0 and a 16-byte aligned output");   \
         switch (kind) {                                                                                                 \
         case EPI_PLAIN: return tr && TR_PLAIN ? LAUNCH<__VA_ARGS__, EPI_PLAIN, true>(a, n, st) : LAUNCH<__VA_ARGS__, EPI_PLAIN>(a, n, st); \
@@ -2533,7 +2537,7 @@ static int launch_conv_rs_epi(const ConvArgs &a, long long ngroups, hipStream_t 
 template <int G, int NCH>
 static int launch_conv_rs(const ConvArgs &a, long long n, hipStream_t st)
 {
-    MMLF_CONV_KIND_SWITCH(launch_conv_rs_epi, false, G, NCH);
+    MMLF_CONV_KIND_SWITCH(launch_conv_rs_epi, false, true, G, NCH);
     return launch_conv_rs_epi<G, NCH, EPI_GENERIC>(a, n, st);
 }
 
@@ -2552,7 +2556,7 @@ static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
         const long long n = ntiles;
         if (a.ref && !a.relu && !a.bn_partial && !a.relu_mask_in && !a.relu_mask_out)
             return launch_conv_x6s_epi<G, PL, EPI_REF_IN>(a, n, st);
-        MMLF_CONV_KIND_SWITCH(launch_conv_x6s_epi, G == 18, G, PL);
+        MMLF_CONV_KIND_SWITCH(launch_conv_x6s_epi, G == 18, G != 18 || a.seg_delta == 0, G, PL);
     }
     // (other widths: the generic build, whose mask words have conv_epilogue16's layout for producer and consumer alike)
     return launch_conv_x6s_epi<G, PL, EPI_GENERIC>(a, ntiles, st);

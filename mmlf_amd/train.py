@@ -86,11 +86,20 @@ def validation_pass(val_model, batches, uncert=False, loss_multimodal=False, mar
     return loss_val_avg / n, mse_avg / n, bad_pix_avg / n
 
 
-def bucket_count(default=10):
-    """MMLF_GRAD_BUCKETS=<n>: how many all-reduces carry the gradient of a step (1 ... 10; default: one per out_net block
-    and stream net).  Fewer, larger messages cost less launch / protocol overhead per byte on point-to-point xGMI links and
-    give the collective's kernels fewer chances to queue behind a running 7 ms persistent convolution; more of them start
-    earlier under backward.  The first multi-GPU run decides; bench.py reports the value in config.buckets."""
+DEFAULT_BUCKETS = 3
+
+
+def bucket_count(default=DEFAULT_BUCKETS):
+    """MMLF_GRAD_BUCKETS=<n>: how many all-reduces carry the gradient of a step (1 ... 10: at most one per out_net block
+    and stream net; default 3).  Fewer, larger messages cost less launch / protocol overhead per byte on point-to-point
+    xGMI links and give the collective's kernels fewer chances to queue behind a running 7 ms persistent convolution;
+    more of them start earlier under backward.  Why 3 and not 10 (the default until round 5): the only place several
+    ranks of this code have run together is the five-rank gloo rehearsal on one GPU, and there ten asynchronous
+    all-reduces in flight per step took 94-106 s per step against 0.41-0.43 s with three
+    (profiles/r05_bench_5rank_gloo_rehearsal.json; the compute-unit cap made no difference) -- a property of that
+    backend's worker threads, maybe, but the message count is the one variable it exposed, and three 6 MB messages leave
+    the same ~2 MB tail behind backward as ten.  The first run on real links decides; bench.py reports the value in
+    config.buckets."""
     import os
     try:
         n = int(os.environ.get('MMLF_GRAD_BUCKETS', default))
@@ -115,7 +124,7 @@ class GradBuckets:
             fine[key] = (min(lo, o), max(hi, o + n))
         # completion order of backward = descending offset in the flat buffer
         self.keys = sorted(fine, key=lambda k: -fine[k][0])
-        n_buckets = bucket_count(len(self.keys)) if n_buckets is None else int(n_buckets)
+        n_buckets = bucket_count() if n_buckets is None else int(n_buckets)
         n_buckets = max(1, min(n_buckets, len(self.keys)))
         # runs of consecutive keys, as even in count as possible (the wide blocks are equal in bytes; the two stream nets
         # together are 5 % of the gradient and share the last run's tail)

@@ -57,10 +57,10 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,buckets', [(2, None), (4, None), (2, '1'), (2, '3')])
+@pytest.mark.parametrize('world,buckets', [(2, None), (4, None), (2, '1'), (2, '10')])
 def test_n_rank_step_equals_manual_average(tmp_path, world, buckets, monkeypatch):
-    """buckets: MMLF_GRAD_BUCKETS -- the gradient carried by one / three all-reduces instead of one per block (round 5:
-    the knob the first 8-GPU run needs); the result must not depend on it"""
+    """buckets: MMLF_GRAD_BUCKETS -- the gradient carried by one all-reduce / one per block instead of the default three
+    (round 5: the knob the first 8-GPU run needs); the result must not depend on it"""
     if buckets is not None:
         monkeypatch.setenv('MMLF_GRAD_BUCKETS', buckets)      # (inherited by the spawned ranks)
     port = _free_port()
@@ -116,12 +116,13 @@ def _global_loss(model, stacks, gt, mask):
 def test_bucket_layout_covers_every_parameter_once():
     m = _make()
     flat, layout = flatten_parameters(m)
-    b = GradBuckets(layout)
+    b = GradBuckets(layout, n_buckets=10)          # the finest division: one bucket per out_net block / stream net
     spans = sorted(b.ranges.values())
     assert spans[0][0] == 0 and spans[-1][1] == flat.numel()
     for (_, hi), (lo, _) in zip(spans, spans[1:]):
         assert hi == lo
     assert set(b.ranges) == {'in_net_hv', 'in_net_id', 'out_net.0', 'out_net.1', 'out_net.2'}
+    assert len(GradBuckets(layout).ranges) == 3    # the default (train.DEFAULT_BUCKETS)
     # parameters are views of the flat buffer and the state_dict is unchanged
     m2 = _make()
     for (k, v), (_, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
@@ -157,7 +158,7 @@ def test_coalesced_buckets_are_contiguous_runs_in_backward_order(n):
 def test_bucket_count_comes_from_the_environment(monkeypatch):
     from mmlf_amd.train import bucket_count
     monkeypatch.delenv('MMLF_GRAD_BUCKETS', raising=False)
-    assert bucket_count(10) == 10
+    assert bucket_count(10) == 10 and bucket_count() == 3
     monkeypatch.setenv('MMLF_GRAD_BUCKETS', '3')
     assert bucket_count(10) == 3
     m = _make()

@@ -92,9 +92,15 @@ def test_a_loss_on_the_posterior_trains_the_network_on_the_native_path(variant):
         loss = (out['posterior'] * wts.to(dev)).sum() + (out['logvar'].sum() if variant == 'dpp' else 0.0)
         loss.backward()
         grads[dev] = {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}
+    # the biases of the convolutions in front of a train-mode BatchNorm have an analytically ZERO gradient (rounding noise
+    # of 1e-14 on both devices): compared in absolute terms; every other tensor relative to its own norm
+    big = max(float(v.norm()) for v in grads['cpu'].values())
+    assert big > 1.0
     worst = 0.0
     for n, ref in grads['cpu'].items():
         got = grads['cuda:0'][n]
-        assert float(ref.abs().max()) > 0, n
-        worst = max(worst, float((got - ref).norm() / ref.norm()))
-    assert worst <= 2e-2, worst          # (float32 trunks on two devices; the head kernels themselves are pinned above at 2e-5)
+        if float(ref.norm()) > 1e-4 * big:
+            worst = max(worst, float((got - ref).norm() / ref.norm()))
+        else:
+            assert n.endswith('.2.bias') and float(got.norm()) <= 1e-6 * big, (n, float(got.norm()))
+    assert worst <= 1e-3, worst          # (float32 trunks on two devices: 1e-5 measured; the head kernels are pinned above at 2e-5)
