@@ -175,7 +175,7 @@ def autograd_leg(variant, B, patch, dev, steps, ref_ms):
     dt = time.time() - t0
     ms = 1e3 * dt / steps
     res = {'value': round(B * steps / dt, 2), 'unit': 'patches/s', 'steps': steps, 'ms_per_step': round(ms, 2),
-           'loss': round(float(val), 6), 'vs_train_step': round(ref_ms / ms, 4) if ref_ms else None}
+           'loss': round(float(val.detach()), 6), 'vs_train_step': round(ref_ms / ms, 4) if ref_ms else None}
     del model, opt, stacks, gt, mask
     torch.cuda.empty_cache()
     return res
