@@ -122,6 +122,9 @@ __device__ __forceinline__ int mmlf_records_left(long long total, long long off)
 #define MMLF_RING16 3   // pipeline depth of the sixteen-wave conv variant (LDS: 30 KB per buffer + 20 KB; 4 measures the same)
 #endif
 #define MMLF_BUF_FLAGS 0x00020000   // raw dword buffer (DATA_FORMAT_32), no swizzle
+// (round 5 measured the epilogue's stores with the non-temporal policy on the 80-column kernels, whose activation lines compete
+// with their own output for an XCD's L2: +12...20 % time on every launch kind, profiles/r05_kbench_nt_store.log -- the L2 is what
+// merges the two 64-byte halves of an output line that two store instructions write; the switch was removed again)
 __device__ __forceinline__ unsigned wave_row_mask(const ConvArgs &a, long long Q0, int w, int lane)
 {
     const unsigned qrow = (unsigned)Q0 + 32 * w + (lane & 31);
