@@ -86,10 +86,12 @@ struct ConvArgs {
 };
 
 // wave-uniform descriptor of what is left of a buffer of `total` bytes behind byte offset `off` (32-bit num_records)
+// (off <= total by construction: every caller's offset is that of a position inside the grid.  Formed in 16-byte units so that
+// shift, minimum and shift back are 32-bit scalar instructions: a 64-bit ordered compare would land on the vector unit.)
 __device__ __forceinline__ int mmlf_records_left(long long total, long long off)
 {
-    const long long left = total - off;
-    return left <= 0 ? 0 : (left > 0x7fffffffll ? 0x7fffffff : (int)left);
+    const unsigned left16 = (unsigned)((unsigned long long)(total - off) >> 4);
+    return (int)((left16 < 0x7ffffffu ? left16 : 0x7ffffffu) << 4);
 }
 
 // epilogue shared by the f32 and the split-bf16 kernels: D[row = position][col = channel]; a lane
@@ -1351,7 +1353,9 @@ struct WgradArgs {
     int cs_in, cin, cs_g, g_shift, P, nsplit, nslice, chunks_per_split, nchunks;
     const float *in_amax, *g_amax;   // f16 split: amax arrays of in and g (common.h)
     const float *chunk_scales;       // f16 split: [nchunks][2] power-of-two operand scales (wgrad_chunk_scales_kernel)
-    long long in_bytes, g_bytes, part_floats;   // what the buffers hold by contract: read by the MMLF_BOUNDS_DEBUG build only
+    long long in_bytes, g_bytes, part_floats;   // what the buffers hold by the ABI's contract: the wide kernel's staging loads are
+                                                // range-checked against in_bytes / g_bytes (buffer descriptors); the rest is read by
+                                                // the MMLF_BOUNDS_DEBUG build only
 };
 
 // Block -> (slice, position split).  Blocks b, b + 8, ... land on one XCD (round-robin dispatch): the slices of one split are
@@ -1567,6 +1571,9 @@ template <int PL> __device__ __forceinline__ WgradScales wgrad_scales(const Wgra
     return s;
 }
 // operand scales of chunk c (PL == 3: no scaling)
+// (Round 5 tried issuing the LOAD of a chunk's scales a whole chunk before their first use -- read at the top of a chunk and used by
+// its first staging piece, the wave waits there for a memory round trip -- and the wide kernel got SLOWER: 8.44 against 7.98 ms on
+// one box, profiles/r05_kbench_wgrad_zeropad.log; the narrow one did not move.  Left as it was.)
 template <int PL> __device__ __forceinline__ void wgrad_chunk_scale(const WgradArgs &a, int c, float &sa, float &sg)
 {
     if constexpr (PL == 2) {
@@ -1832,6 +1839,14 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
             for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
 
     float4 ra[NA], rg[NG];
+    // Input channels past cs_in and gradient columns past cs_g (the slices' and the 288 columns' padding) are staged as COPIES of
+    // the tensor's last four channels (the clamped load) instead of zeros: they only feed accumulator rows / columns that
+    // wgrad_reduce_kernel never reads (ci > Cin, co >= Cout), the copies are in-range values (no f16 overflow), and the ones row
+    // (ci == Cin) is patched in WW_STORE_A either way.  Four selects per staging piece less (round 5;
+    // -DMMLF_WGRAD_ZEROPAD=1 builds the zero-filling form: profiles/r05_kbench_wgrad_zeropad.log).
+#ifndef MMLF_WGRAD_ZEROPAD
+#define MMLF_WGRAD_ZEROPAD 0
+#endif
     // staging items are clamped to the last one instead of predicated: surplus threads load and store that
     // item again (same value), which keeps the loop free of branches.  Also of SCALAR ones: round 5 let the waves whose
     // items of a piece are all surplus (3 of 8 on the second activation piece, 4 of 8 on the fifth gradient piece at <3, 9>)
@@ -1839,25 +1854,49 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     // (profiles/r05_kbench_wgrad_surplus.log): a branch per column block ends the basic block the MFMAs and the staging
     // instructions are interleaved in.  Nor do the surplus lanes' stores to ONE address cost anything: giving every such lane
     // an LDS slot of its own measured 8.04 ms against 8.02 (profiles/r05_kbench_wgrad_surplus.log) -- equal addresses merge.
+    // Per-lane parts of every staging address, formed ONCE: the byte offset of a piece's item from its chunk's first position
+    // (32 bits: the load is `global_load_dwordx4 v, v_offset, s[base]`, no vector arithmetic per load) and its byte offset
+    // inside an LDS buffer.  Round 5: with the addresses recomputed from 64-bit terms in the loop and the padding channels
+    // zero-filled by selects, a chunk had 136 vector instructions per wave next to its 81 MFMAs; the vector-issue port is what
+    // this kernel runs out of (each one removed is ~0.01 ms per launch: profiles/r05_kbench_wgrad_zeropad.log).
+    unsigned ga_off[NA], gg_off[NG];
+    int la_off[NA], lg_off[NG], a_ch[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int idx = min(tid + 512 * j, 66 * FA - 1);
+        const int row = idx / FA, f = idx - row * FA;
+        const int seg = row >= 33, pix = row - 33 * seg;
+        a_ch[j] = ci0 + 4 * f;
+        ga_off[j] = (unsigned)((seg * a.P + pix) * a.cs_in + min(ci0 + 4 * f, a.cs_in - 4)) * 4u;
+        la_off[j] = seg * PL * A_PLANE + pix * ROWA + 8 * f;
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int idx = min(tid + 512 * j, WG_KQ * FG - 1);
+        const int row = idx / FG, f = idx - row * FG;
+        gg_off[j] = (unsigned)((a.g_shift + row) * a.cs_g + min(4 * f, a.cs_g - 4)) * 4u;
+        lg_off[j] = A_BYTES + row * ROWG + 8 * f;
+    }
+    const char *const in_b = reinterpret_cast<const char *>(a.in), *const g_b = reinterpret_cast<const char *>(a.g);
 #define WW_GLOAD_A(j, c)                                                                                    \
     do {                                                                                                    \
-        const long long Qc = (long long)(c) * WG_KQ;                                                        \
-        const int idx = min(tid + 512 * (j), 66 * FA - 1);                                                  \
-        const int row = idx / FA, f = idx - row * FA;                                                       \
-        const int seg = row >= 33, pix = row - 33 * seg;                                                    \
-        const int ch = min(ci0 + 4 * f, a.cs_in - 4);                                                       \
-        MMLF_OOB(OOB_WG_IN, ((Qc + seg * a.P + pix) * a.cs_in + ch + 4) * 4ll > a.in_bytes);             \
-        const float4 v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
-        ra[j] = (ci0 + 4 * f < a.cs_in) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                              \
+        const long long cb_ = (long long)(c) * WG_KQ * a.cs_in * 4;      /* wave-uniform */                   \
+        MMLF_OOB(OOB_WG_IN, cb_ + ga_off[j] + 16 > a.in_bytes);                                             \
+        /* buffer load on a per-chunk descriptor: base and what is left of the tensor in scalar registers, the lane's */ \
+        /* 32-bit offset as is -- no vector address arithmetic, and the address unit range-checks the access          */ \
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                               \
+            const_cast<char *>(in_b + cb_), 0, mmlf_records_left(a.in_bytes, cb_), MMLF_BUF_FLAGS);         \
+        const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_, ga_off[j], 0, 0)); \
+        ra[j] = (MMLF_WGRAD_ZEROPAD && !(a_ch[j] < a.cs_in)) ? make_float4(0.f, 0.f, 0.f, 0.f) : v;         \
     } while (0)
 #define WW_GLOAD_G(j, c)                                                                                    \
     do {                                                                                                    \
-        const long long Qc = (long long)(c) * WG_KQ;                                                        \
-        const int idx = min(tid + 512 * (j), WG_KQ * FG - 1);                                               \
-        const int row = idx / FG, f = idx - row * FG;                                                       \
-        MMLF_OOB(OOB_WG_G, ((Qc + a.g_shift + row) * a.cs_g + min(4 * f, a.cs_g - 4) + 4) * 4ll > a.g_bytes); \
-        const float4 v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + min(4 * f, a.cs_g - 4)); \
-        rg[j] = (4 * f < a.cs_g) ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+        const long long cb_ = (long long)(c) * WG_KQ * a.cs_g * 4;                                          \
+        MMLF_OOB(OOB_WG_G, cb_ + gg_off[j] + 16 > a.g_bytes);                                               \
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                               \
+            const_cast<char *>(g_b + cb_), 0, mmlf_records_left(a.g_bytes, cb_), MMLF_BUF_FLAGS);           \
+        const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_, gg_off[j], 0, 0)); \
+        rg[j] = (MMLF_WGRAD_ZEROPAD && !(lg_off[j] - A_BYTES - (lg_off[j] - A_BYTES) / ROWG * ROWG < 2 * a.cs_g)) ? make_float4(0.f, 0.f, 0.f, 0.f) : v; \
     } while (0)
 #define WW_GLOAD(c)                                                                                         \
     do {                                                                                                    \
@@ -1866,27 +1905,22 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     } while (0)
 #define WW_STORE_A(j, dst)                                                                                  \
     do {                                                                                                    \
-        const int idx = min(tid + 512 * (j), 66 * FA - 1);                                                  \
-        const int row = idx / FA, f = idx - row * FA;                                                       \
-        const int seg = row >= 33, pix = row - 33 * seg;                                                    \
         float4 v = ra[j];                 /* ones row -> bias gradient */                                   \
-        const int ch = ci0 + 4 * f;                                                                         \
-        v.x = ch == a.cin ? sc.inv_sa : v.x;   /* = 1 after scaling */                                                                      \
-        v.y = ch + 1 == a.cin ? sc.inv_sa : v.y;                                                                  \
-        v.z = ch + 2 == a.cin ? sc.inv_sa : v.z;                                                                  \
-        v.w = ch + 3 == a.cin ? sc.inv_sa : v.w;                                                                  \
-        split_store4_pl<PL>(v, st_sa, (dst) + seg * PL * A_PLANE + pix * ROWA + 8 * f, A_PLANE);            \
+        const int ch = a_ch[j];                                                                             \
+        v.x = ch == a.cin ? sc.inv_sa : v.x;   /* = 1 after scaling */                                      \
+        v.y = ch + 1 == a.cin ? sc.inv_sa : v.y;                                                            \
+        v.z = ch + 2 == a.cin ? sc.inv_sa : v.z;                                                            \
+        v.w = ch + 3 == a.cin ? sc.inv_sa : v.w;                                                            \
+        split_store4_pl<PL>(v, st_sa, (dst) + la_off[j], A_PLANE);                                          \
     } while (0)
 #define WW_STORE_G(j, dst)                                                                                  \
     do {                                                                                                    \
-        const int idx = min(tid + 512 * (j), WG_KQ * FG - 1);                                               \
-        const int row = idx / FG, f = idx - row * FG;                                                       \
         if (MMLF_ABL_WGRAD_STAGE == 1 && PL == 2) {      /* ablation: the same bytes, no split */            \
-            char *p0_ = (dst) + A_BYTES + row * ROWG + 8 * f;                                               \
+            char *p0_ = (dst) + lg_off[j];                                                                  \
             *reinterpret_cast<uint2 *>(p0_) = make_uint2(__float_as_uint(rg[j].x), __float_as_uint(rg[j].y)); \
             *reinterpret_cast<uint2 *>(p0_ + G_PLANE) = make_uint2(__float_as_uint(rg[j].z), __float_as_uint(rg[j].w)); \
         } else {                                                                                            \
-            split_store4_pl<PL>(rg[j], st_sg, (dst) + A_BYTES + row * ROWG + 8 * f, G_PLANE);               \
+            split_store4_pl<PL>(rg[j], st_sg, (dst) + lg_off[j], G_PLANE);                                  \
         }                                                                                                   \
     } while (0)
 
