@@ -1847,6 +1847,7 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
 #ifndef MMLF_WGRAD_ZEROPAD
 #define MMLF_WGRAD_ZEROPAD 0
 #endif
+
     // staging items are clamped to the last one instead of predicated: surplus threads load and store that
     // item again (same value), which keeps the loop free of branches.  Also of SCALAR ones: round 5 let the waves whose
     // items of a piece are all surplus (3 of 8 on the second activation piece, 4 of 8 on the fifth gradient piece at <3, 9>)
@@ -2015,6 +2016,9 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
         static_assert(NA + NG <= NBH, "one staging piece per column block");
         for (int c = c_begin; c + 1 < c_end; ++c) {
             wgrad_chunk_scale<PL>(a, c + 1, st_sa, st_sg);
+            // (the scalar branch around each of the seven reloads stays: with unconditional loads -- the split's last chunk loaded
+            // once more, never staged -- the chunk is one basic block and the compiler's own order of it is 1.7 % SLOWER, 8.17
+            // against 8.04 ms, profiles/r05_kbench_wgrad_zeropad.log; the branches are what pins the interleaving written here)
             const bool reload = c + 2 < c_end;
             WW_CHUNK(true, reload);
             if constexpr (!EARLY) __syncthreads();
