@@ -1674,36 +1674,43 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
 
+    // MMLF_WGRADN_CLAMP (round 5): staging items and channels past the tile are CLAMPED -- surplus threads load and store the last
+    // item again, padding channels are copies of the tensor's last four -- instead of predicated and zero-filled: no divergent
+    // branch per piece; the padding only feeds accumulator rows / columns the reduction never reads (as in the wide kernel).
+#ifndef MMLF_WGRADN_CLAMP
+#define MMLF_WGRADN_CLAMP 1
+#endif
     float4 ra[NA], rg[NG];
 #define WN_GLOAD(c)                                                                                         \
     do {                                                                                                    \
         const long long Qc = (long long)(c) * WG_KQ;                                                        \
         _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
-            const int idx = tid + 256 * j;                                                                  \
+            const int idx = MMLF_WGRADN_CLAMP ? min(tid + 256 * j, 66 * FA - 1) : tid + 256 * j;            \
             const int row = idx / FA, f = idx - row * FA;                                                   \
             const int seg = row >= 33, pix = row - 33 * seg;                                                \
-            const int ch = ci0 + 4 * f;                                                                     \
+            const int ch = MMLF_WGRADN_CLAMP ? min(ci0 + 4 * f, a.cs_in - 4) : ci0 + 4 * f;                 \
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
             MMLF_OOB(OOB_WG_IN, idx < 66 * FA && ch < a.cs_in && ((Qc + seg * a.P + pix) * a.cs_in + ch + 4) * 4ll > a.in_bytes); \
-            if (idx < 66 * FA && ch < a.cs_in)                                                              \
+            if (MMLF_WGRADN_CLAMP || (idx < 66 * FA && ch < a.cs_in))                                       \
                 v = *reinterpret_cast<const float4 *>(a.in + (size_t)(Qc + seg * a.P + pix) * a.cs_in + ch); \
             ra[j] = v;                                                                                      \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
-            const int idx = tid + 256 * j;                                                                  \
+            const int idx = MMLF_WGRADN_CLAMP ? min(tid + 256 * j, WG_KQ * FG - 1) : tid + 256 * j;         \
             const int row = idx / FG, f = idx - row * FG;                                                   \
+            const int gc = MMLF_WGRADN_CLAMP ? min(4 * f, a.cs_g - 4) : 4 * f;                              \
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                     \
-            MMLF_OOB(OOB_WG_G, idx < WG_KQ * FG && 4 * f < a.cs_g && ((Qc + a.g_shift + row) * a.cs_g + 4 * f + 4) * 4ll > a.g_bytes); \
-            if (idx < WG_KQ * FG && 4 * f < a.cs_g)                                                         \
-                v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + 4 * f); \
+            MMLF_OOB(OOB_WG_G, idx < WG_KQ * FG && gc < a.cs_g && ((Qc + a.g_shift + row) * a.cs_g + gc + 4) * 4ll > a.g_bytes); \
+            if (MMLF_WGRADN_CLAMP || (idx < WG_KQ * FG && 4 * f < a.cs_g))                                  \
+                v = *reinterpret_cast<const float4 *>(a.g + (size_t)(Qc + a.g_shift + row) * a.cs_g + gc);  \
             rg[j] = v;                                                                                      \
         }                                                                                                   \
     } while (0)
 #define WN_LSTORE()                                                                                         \
     do {                                                                                                    \
         _Pragma("unroll") for (int j = 0; j < NA; ++j) {                                                    \
-            const int idx = tid + 256 * j;                                                                  \
-            if (idx < 66 * FA) {                                                                            \
+            const int idx = MMLF_WGRADN_CLAMP ? min(tid + 256 * j, 66 * FA - 1) : tid + 256 * j;            \
+            if (MMLF_WGRADN_CLAMP || idx < 66 * FA) {                                                       \
                 const int row = idx / FA, f = idx - row * FA;                                               \
                 const int seg = row >= 33, pix = row - 33 * seg;                                            \
                 float4 v = ra[j];         /* ones row (bias gradient): patched here, not at load time, */ \
@@ -1716,8 +1723,8 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
             }                                                                                               \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < NG; ++j) {                                                    \
-            const int idx = tid + 256 * j;                                                                  \
-            if (idx < WG_KQ * FG) {                                                                         \
+            const int idx = MMLF_WGRADN_CLAMP ? min(tid + 256 * j, WG_KQ * FG - 1) : tid + 256 * j;         \
+            if (MMLF_WGRADN_CLAMP || idx < WG_KQ * FG) {                                                    \
                 const int row = idx / FG, f = idx - row * FG;                                               \
                 split_store4_pl<PL>(rg[j], st_sg, Gs + row * ROWG + 8 * f, G_PLANE);                        \
             }                                                                                               \
