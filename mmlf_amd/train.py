@@ -139,14 +139,12 @@ class GradBuckets:
                 self.bucket_of[k] = run[-1]
         self.pending = []
         self.done = set()
-        self.seen = set()
         self.wait_events = None      # bench.py: a list that receives (start, end) HIP events around each step's waits
 
     def ready(self, flat_grad, key):
         """backward has enqueued every gradient of `key`: fire its bucket if that completes the bucket's run"""
         if key not in self.bucket_of:
             return
-        self.seen.add(key)
         last = self.bucket_of[key]
         if last in self.done or key != last:
             return
@@ -170,7 +168,7 @@ class GradBuckets:
         if timed:
             e1.record()
             self.wait_events.append((e0, e1))
-        self.pending, self.done, self.seen = [], set(), set()
+        self.pending, self.done = [], set()
 
 
 class TrainStep:
