@@ -148,7 +148,9 @@ int mmlf_conv2x2_h2(const float *in, int cs_in, int K, const void *packed, const
                     uint32_t *relu_mask_out /* nullable */, const uint32_t *relu_mask_in /* nullable */, void *stream);
 /* ReLU masks as bits (mmlf_relu_mask_words(B,H,W) words): relu_mask_out receives (out > 0) of every element of
  * this launch; relu_mask_in -- the mask a launch with the same (B,H,W) and N wrote -- replaces relu_ref in the data
- * gradient (nn.ReLU backward, feed_forward.py:124): the layer's activations are not read again. */
+ * gradient (nn.ReLU backward, feed_forward.py:124): the layer's activations are not read again.  The word layout is private
+ * to the library (it depends on the kernel and orientation a (B,H,W,N) launch takes: csrc/conv.hip); a caller only carries the
+ * buffer from the producing launch to the consuming one. */
 int64_t mmlf_relu_mask_words(int B, int H, int W);
 /* number of workgroups mmlf_conv2x2_h2 launches for K input and N output channels on this grid (= rows of bn_partial) */
 int mmlf_conv2x2_blocks(int K, int N, int B, int H, int W);
