@@ -64,6 +64,18 @@ template <> struct VecIO<4> {
             load(p, o);
         }
     }
+    // the same with the alignment decided once per launch by the caller (a scalar branch, no per-lane address test)
+    static __device__ __forceinline__ void load_nt(const float *p, float *o, bool is_aligned)
+    {
+        if (is_aligned) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        } else {
+            const float2 a = *reinterpret_cast<const float2 *>(p), b = *reinterpret_cast<const float2 *>(p + 2);
+            o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+        }
+    }
     static __device__ __forceinline__ void store_nt(float *p, const float *o)
     {
         if (aligned(p)) {
@@ -78,7 +90,7 @@ template <> struct VecIO<4> {
 
 // V = channels per thread access (4; slices that are only 8-byte aligned go through VecIO<4>'s two-float2 form).
 template <bool BWD, int V>
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ z, int cs_z,
+__device__ __forceinline__ void bn_reduce_body(const float *__restrict__ z, int cs_z,
                                                         const float *__restrict__ gy, int cs_gy, int c_off,
                                                         const float *__restrict__ scale,
                                                         const float *__restrict__ shift,
@@ -93,40 +105,65 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
     const int pl = tid / cvn, cg = tid - pl * cvn;
     const bool active = pl < ppi;
     double s0[V], s1[V];
-    float sc[V], sh[V], mu[V], iv[V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) { s0[e] = 0; s1[e] = 0; sc[e] = sh[e] = mu[e] = iv[e] = 0.f; }
-    if (BWD && active) {
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const int c = V * cg + e;
-            if (c < C) { sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; iv[e] = invstd[c]; }
+    for (int e = 0; e < V; ++e) { s0[e] = 0; s1[e] = 0; }
+    // One LDS block, two uses: the backward pass keeps its four per-channel coefficients here while it streams (re-read per
+    // position, NOT held in registers: with them the kernel needs 62 VGPRs, without 48 or fewer -- what is left per SIMD beside
+    // the two waves of a wide weight-gradient workgroup, so that this HBM-bound pass can run under that matrix-core-bound one,
+    // engine.py OVERLAP_WGRAD); afterwards the block's cross-thread sums.
+    __shared__ double red[2][256][V];
+    float *cf = reinterpret_cast<float *>(&red[0][0][0]);          // [4][256 * V] floats = half of red
+    if (BWD) {
+        for (int c = tid; c < cvn * V; c += 256) {
+            const bool in = c < C;
+            cf[0 * 256 * V + c] = in ? scale[c] : 0.f;
+            cf[1 * 256 * V + c] = in ? shift[c] : 0.f;
+            cf[2 * 256 * V + c] = in ? mean[c] : 0.f;
+            cf[3 * 256 * V + c] = in ? invstd[c] : 0.f;
         }
+        __syncthreads();
     }
     const int nrows = B * H;
+    // every access of the launch is 16-byte aligned, or none is promised to be (channel slices of the concat buffer)
+    const bool z_aligned = V == 4 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (cs_z & 3) == 0;
+    const bool g_aligned = V == 4 && BWD && (reinterpret_cast<uintptr_t>(gy + c_off) & 15) == 0 && (cs_gy & 3) == 0;
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int b = row / H, y = row - b * H + 1;
         const size_t base = ((size_t)(b * R + y) * P + 1);  // first interior position of the row
         for (int x = pl; active && x < W; x += ppi) {
             float zz[V];
-            VecIO<V>::load_nt(z + (base + x) * cs_z + V * cg, zz);
+            VecIO<V>::load_nt(z + (base + x) * cs_z + V * cg, zz, z_aligned);
             if (!BWD) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) { s0[e] += zz[e]; s1[e] += (double)zz[e] * zz[e]; }
             } else {
                 float gg[V];
-                VecIO<V>::load_nt(gy + (base + x) * cs_gy + c_off + V * cg, gg);
+                VecIO<V>::load_nt(gy + (base + x) * cs_gy + c_off + V * cg, gg, g_aligned);
+                // the coefficient reads stay inside the loop and come a few at a time (the barriers): registers, see above
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float u = fmaf(zz[e], sc[e], sh[e]);
-                    const float g = u > 0.f ? gg[e] : 0.f;
-                    s0[e] += g;
-                    s1[e] += (double)g * (double)((zz[e] - mu[e]) * iv[e]);
+                for (int h = 0; h < V; h += 2) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int e = h; e < h + 2 && e < V; ++e) {
+                        const float sc = cf[0 * 256 * V + V * cg + e], sh = cf[1 * 256 * V + V * cg + e];
+                        const float u = fmaf(zz[e], sc, sh);
+                        gg[e] = u > 0.f ? gg[e] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < V; h += 2) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int e = h; e < h + 2 && e < V; ++e) {
+                        const float mu = cf[2 * 256 * V + V * cg + e], iv = cf[3 * 256 * V + V * cg + e];
+                        s0[e] += gg[e];
+                        s1[e] += (double)gg[e] * (double)((zz[e] - mu) * iv);
+                    }
                 }
             }
         }
     }
-    __shared__ double red[2][256][V];
+    __syncthreads();                                                // every wave is done with the coefficients
 #pragma unroll
     for (int e = 0; e < V; ++e) { red[0][tid][e] = s0[e]; red[1][tid][e] = s1[e]; }
     __syncthreads();
@@ -142,6 +179,25 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
             }
         }
     }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ z, int cs_z, const float *__restrict__ gy, int cs_gy,
+                                                        int c_off, const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        const float *__restrict__ mean, const float *__restrict__ invstd, int C,
+                                                        double *__restrict__ partial, int B, int H, int W)
+{
+    bn_reduce_body<false, V>(z, cs_z, gy, cs_gy, c_off, scale, shift, mean, invstd, C, partial, B, H, W);
+}
+
+// The backward sums, held to 48 registers (the attribute is not taken from a template, hence the plain kernel): that is what
+// a SIMD has left beside the two waves of a wide weight-gradient workgroup (2 x 232 of 512).
+__global__ __launch_bounds__(256)
+void bn_reduce_bwd_kernel(const float *__restrict__ z, int cs_z, const float *__restrict__ gy, int cs_gy, int c_off,
+                          const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
+                          const float *__restrict__ invstd, int C, double *__restrict__ partial, int B, int H, int W)
+{
+    bn_reduce_body<true, 4>(z, cs_z, gy, cs_gy, c_off, scale, shift, mean, invstd, C, partial, B, H, W);
 }
 
 // one wave per channel: lanes stride over the per-block partials, then a shuffle reduction
@@ -1168,7 +1224,7 @@ extern "C" int mmlf_bn_stats_train(const float *z, int cs, int C, const float *g
     MMLF_CHECK_ARG(cs % 4 == 0 && C > 0 && C <= cs && (C + 3) / 4 <= 256, "mmlf_bn_stats_train: C=%d cs=%d", C, cs);
     MMLF_CHECK_ARG(nblocks > 0 && nblocks <= 4096, "mmlf_bn_stats_train: nblocks=%d", nblocks);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((bn_reduce_kernel<false, 4>), dim3(nblocks), dim3(256), 0, st, z, cs, nullptr, 0, 0, nullptr,
+    hipLaunchKernelGGL((bn_reduce_kernel<4>), dim3(nblocks), dim3(256), 0, st, z, cs, nullptr, 0, 0, nullptr,
                        nullptr, nullptr, nullptr, C, partial, B, H, W);
     const double n = (double)B * H * W;
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, st, partial, nblocks, C, n, gamma,
@@ -1252,7 +1308,7 @@ extern "C" int mmlf_bn_bwd_reduce(const float *gy, int cs_gy, int c_off, const f
                    "mmlf_bn_bwd_reduce: layout");
     MMLF_CHECK_ARG(nblocks > 0 && nblocks <= 4096, "mmlf_bn_bwd_reduce: nblocks=%d", nblocks);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((bn_reduce_kernel<true, 4>), dim3(nblocks), dim3(256), 0, st, z, cs_z, gy, cs_gy, c_off,
+    hipLaunchKernelGGL(bn_reduce_bwd_kernel, dim3(nblocks), dim3(256), 0, st, z, cs_z, gy, cs_gy, c_off,
                        scale, shift, save_mean, save_invstd, C, partial, B, H, W);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, partial, nblocks, C,
                        (double)B * H * W, gamma, save_invstd, dgamma, dbeta, accumulate, coef);

@@ -1,0 +1,63 @@
+#!/bin/bash
+# Memory-side bytes of the step's launch kinds from gfx950's 32-byte-unit request counters (TCC_EA0_RDREQ_DRAM_32B: a 64-byte
+# request counts 2, a 128-byte one 4; TCC_EA0_WRREQ_WRITE_DRAM_32B likewise), beside what FETCH_SIZE / WRITE_SIZE are built from
+# (TCC_EA0_RDREQ, _32B, TCC_BUBBLE = 128-byte requests).  Calibration in the same passes: a torch device copy and the BatchNorm
+# row passes of tools/bn_bench.py, whose bytes are known.  Separate --pmc passes, kernel trace only.
+#   gpurun -- bash tools/pmc_exact.sh        -> gpurun_out/pmc_exact/summary.json
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/pmc_exact
+mkdir -p $OUT
+pass() {  # prog name counters...
+  prog=$1; name=$2; shift; shift
+  if [ $prog = k ]; then
+    timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$prog$name -- python3 tools/kbench.py 512 3 pmc > $OUT/$prog$name.log 2>&1
+  else
+    timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$prog$name -- python3 tools/bn_bench.py 512 pmc > $OUT/$prog$name.log 2>&1
+  fi
+  echo "pass $prog$name rc=$?"
+}
+for prog in b k; do
+  pass $prog r TCC_EA0_RDREQ_DRAM_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum &&
+  pass $prog w TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum || exit 1
+done
+python3 - <<'PY'
+import csv, glob, json, collections
+out = collections.defaultdict(dict)
+for prog in 'bk':
+  for d in 'rw':
+    try:
+        rows = list(csv.DictReader(open(glob.glob(f'gpurun_out/pmc_exact/{prog}{d}/*/*_counter_collection.csv')[0])))
+        kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(f'gpurun_out/pmc_exact/{prog}{d}/*/*_kernel_trace.csv')[0]))}
+    except Exception as e:
+        print('pass', prog, d, 'failed', e); continue
+    s = collections.defaultdict(float); n = collections.defaultdict(set); dur = collections.defaultdict(float)
+    for r in rows:
+        k = r['Kernel_Name'].split('(')[0]
+        t = kt[r['Dispatch_Id']]
+        ns = int(t['End_Timestamp']) - int(t['Start_Timestamp'])
+        if ns < 300000:          # the small launches (fills, packs, reductions) are not what is asked
+            continue
+        # the same template runs several shapes (70 -> 70 and 27 -> 70; 280 and 70 channel rows): keep them apart by duration class
+        k = f'{prog}:{k} ~{ns / 1e6:.1f}ms' if 'bn_' in k or 'copy' in k.lower() or 'elementwise' in k else f'{prog}:{k}'
+        s[(k, r['Counter_Name'])] += float(r['Counter_Value'])
+        if r['Dispatch_Id'] not in n[k]:
+            n[k].add(r['Dispatch_Id']); dur[k] += ns
+    for (k, c), v in s.items():
+        out[k][c] = v / len(n[k])
+        out[k][f'avg_ms_{d}'] = round(dur[k] / len(n[k]) / 1e6, 4)
+        out[k][f'launches_{d}'] = len(n[k])
+for k, v in out.items():
+    if 'TCC_EA0_RDREQ_DRAM_32B_sum' in v:
+        v['read_GB_exact'] = round(v['TCC_EA0_RDREQ_DRAM_32B_sum'] * 32 / 1e9, 4)
+        b, r, r32 = v.get('TCC_BUBBLE_sum', 0), v.get('TCC_EA0_RDREQ_sum', 0), v.get('TCC_EA0_RDREQ_32B_sum', 0)
+        v['read_GB_fetch_size_formula'] = round((b * 128 + (r - b - r32) * 64 + r32 * 32) / 1e9, 4)
+        v['read_GB_rdreq_x64'] = round(r * 64 / 1e9, 4)
+    if 'TCC_EA0_WRREQ_WRITE_DRAM_32B_sum' in v:
+        v['write_GB_exact'] = round(v['TCC_EA0_WRREQ_WRITE_DRAM_32B_sum'] * 32 / 1e9, 4)
+        w, w64 = v.get('TCC_EA0_WRREQ_sum', 0), v.get('TCC_EA0_WRREQ_64B_sum', 0)
+        v['write_GB_write_size_formula'] = round((w64 * 64 + (w - w64) * 32) / 1e9, 4)
+json.dump(out, open('gpurun_out/pmc_exact/summary.json', 'w'), indent=1, sort_keys=True)
+for k in sorted(out):
+    v = out[k]
+    print(k, {c: v[c] for c in v if c.startswith(('read_GB', 'write_GB', 'avg_ms', 'launches'))})
+PY
