@@ -46,7 +46,7 @@ int mmlf_abi_version(void);
 
 /* What the binary is: one line with the ABI version, the source revision it was built from and the value of every build
  * switch that changes behaviour ("abi=7 git=... MMLF_ABL_TERMS=3 ... ablation=0").  mmlf_build_is_ablation() is nonzero for a
- * build that computes WRONG results by construction (the timing ablations of csrc/conv.hip): a binding must refuse such a
+ * build that computes WRONG results by construction (the timing ablations, switches in csrc/conv_device.h): a binding must refuse such a
  * library unless its user asked for it (mmlf_amd/_lib.py: MMLF_ALLOW_ABLATION=1). */
 const char *mmlf_build_info(void);
 int mmlf_build_is_ablation(void);
@@ -55,7 +55,7 @@ int mmlf_build_is_ablation(void);
 int mmlf_conv_cus(void);
 
 /* Bounds audit: END (largest byte offset + 1) of what ONE launch of mmlf_conv2x2_h2 / mmlf_conv2x2_wgrad_h2 of the given
- * shape may touch behind each of its pointer arguments, derived from the launch geometry (csrc/conv.hip, end of file).
+ * shape may touch behind each of its pointer arguments, derived from the launch geometry (end of csrc/conv.hip and csrc/wgrad.hip).
  * A caller that allocates what the size queries below say is inside every end: tests/test_bounds_audit.py asserts it. */
 enum { MMLF_AUDIT_IN = 0, MMLF_AUDIT_PACKED = 1, MMLF_AUDIT_BIAS = 2, MMLF_AUDIT_OUT = 3, MMLF_AUDIT_REF = 4,
        MMLF_AUDIT_IN_AMAX = 5, MMLF_AUDIT_OUT_AMAX = 6, MMLF_AUDIT_BN_PARTIAL = 7, MMLF_AUDIT_MASK = 8, MMLF_AUDIT_CONV_N = 9 };

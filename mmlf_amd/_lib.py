@@ -96,7 +96,7 @@ BUILD_INFO = None
 
 def validate(lib, path, environ=None):
     """Refuse a library this package must not call: another ABI version (its entry points would be called with shifted
-    arguments) or a build that computes WRONG results by construction -- the timing ablations of csrc/conv.hip
+    arguments) or a build that computes WRONG results by construction -- the timing ablations whose switches csrc/conv_device.h lists
     (`mmlf_build_is_ablation()`), unless MMLF_ALLOW_ABLATION=1 says the user wants exactly that (kernel A/B runs).
     `lib` is anything with the three entry points (the tests pass a stub).  Returns the build string."""
     environ = os.environ if environ is None else environ

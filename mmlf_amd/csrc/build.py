@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['conv.hip', 'elementwise.hip']
+SOURCES = ['conv.hip', 'wgrad.hip', 'elementwise.hip']
 LIB = os.path.join(HERE, 'libmmlf_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -ffp-contract=off: elementwise kernels restate float32 expressions of the reference op by op
@@ -16,7 +16,7 @@ def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SOURCES + ['common.h', 'build.py', os.path.join('..', '..', 'include', 'mmlf_hip.h')]
+    deps = SOURCES + ['common.h', 'conv_device.h', 'build.py', os.path.join('..', '..', 'include', 'mmlf_hip.h')]
     return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in deps)
 
 
@@ -39,14 +39,17 @@ def build(force=False, verbose=True, extra_flags=(), lib=None):
     lib = lib or LIB
     tag = '' if lib == LIB else '.' + os.path.basename(lib).replace('.so', '')
     flags = [*FLAGS, f'-DMMLF_GIT_HASH="{source_revision()}"', *extra_flags]
-    objs = []
-    for src in SOURCES:
+    objs, jobs = [], []
+    for src in SOURCES:                 # the translation units are independent: compiled side by side
         obj = os.path.join(os.path.dirname(lib), src.replace('.hip', tag + '.o'))
         cmd = [HIPCC, *flags, '-c', os.path.join(HERE, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        jobs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
+    failed = [cmd for cmd, job in jobs if job.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', lib]
     if verbose:
         print(' '.join(cmd), flush=True)

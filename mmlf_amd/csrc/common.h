@@ -68,7 +68,7 @@ static inline int mmlf_allow_lds(const void *kernel, size_t bytes, const char *w
 // buffers hold (slot = which argument; tests/test_gpu_bounds.py builds such a library on the GPU box, runs the launch kinds of
 // a training step and of tools/kbench.py through it and expects zeros).  Off in the product build: the macro is empty.
 #ifdef MMLF_BOUNDS_DEBUG
-extern __device__ unsigned long long g_mmlf_oob[8];
+static __device__ unsigned long long g_mmlf_oob[8];   // one per translation unit (no relocatable device code)
 #define MMLF_OOB(slot, cond) do { if (cond) atomicAdd(&g_mmlf_oob[slot], 1ull); } while (0)
 #else
 #define MMLF_OOB(slot, cond) do { } while (0)

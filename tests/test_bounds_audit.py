@@ -4,7 +4,7 @@ host-side extent derivations of the library are called).
 Why it exists: in round 4 one invocation of tools/kbench.py died with `Memory access fault by GPU` 0.3 s after its first
 GPU activity and the identical command passed on the next lease.  The cause could not be reproduced, so every launch that
 tool makes before its first timed loop -- and every launch kind of a training step -- has its extents DERIVED
-(mmlf_audit_conv_h2 / mmlf_audit_wgrad_h2, csrc/conv.hip) and held here against what the ABI's size queries tell a caller
+(mmlf_audit_conv_h2 / mmlf_audit_wgrad_h2, csrc/conv.hip and csrc/wgrad.hip) and held here against what the ABI's size queries tell a caller
 to allocate, over a sweep of shapes (training patches, tiny images, non-square frames, full 512x512 frames; every channel
 combination the network has).  tests/test_gpu_bounds.py is the GPU half: a -DMMLF_BOUNDS_DEBUG build counts real accesses.
 

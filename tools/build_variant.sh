@@ -8,8 +8,9 @@ name=$1; shift
 mkdir -p variants
 FL="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-function -ffp-contract=off"
 /opt/rocm/bin/hipcc $FL "$@" -c mmlf_amd/csrc/conv.hip -o variants/conv_$name.o &
+/opt/rocm/bin/hipcc $FL "$@" -c mmlf_amd/csrc/wgrad.hip -o variants/wgrad_$name.o &
 /opt/rocm/bin/hipcc $FL "$@" -c mmlf_amd/csrc/elementwise.hip -o variants/ew_$name.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC variants/conv_$name.o variants/ew_$name.o -o variants/lib_$name.so
-rm -f variants/conv_$name.o variants/ew_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC variants/conv_$name.o variants/wgrad_$name.o variants/ew_$name.o -o variants/lib_$name.so
+rm -f variants/conv_$name.o variants/wgrad_$name.o variants/ew_$name.o
 echo variants/lib_$name.so
