@@ -1372,11 +1372,13 @@ static bool conv_sixteen_waves(int planes, int np, const Grid &g)
 // The transposed epilogue (conv_epilogue16_tr) serves the launch kinds plain / ReLU / ReLU + mask-out / mask-in when the
 // output rows can take 16-byte stores.  MMLF_CONV_TR=0 turns it off for the whole process (A/B; the ReLU mask words then
 // have the other layout, for their producer and their consumer alike).
-static bool conv_tr_enabled()
+static int conv_tr_mode()
 {
     static const int on = [] { const char *e = getenv("MMLF_CONV_TR"); return e ? atoi(e) : 1; }();
-    return on != 0;
+    return on;
 }
+static bool conv_tr_enabled() { return conv_tr_mode() != 0; }
+static bool conv_tr_any_shape() { return conv_tr_mode() == 2; }     // 2: also where the geometry rule says no (A/B)
 static bool conv_tr_fits(const ConvArgs &a)
 {
     return a.n_store % 4 == 0 && a.cs_out % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
@@ -1491,7 +1493,7 @@ static int launch_conv_x6s(const ConvArgs &a, long long ntiles, hipStream_t st)
         const long long n = ntiles;
         if (a.ref && !a.relu && !a.bn_partial && !a.relu_mask_in && !a.relu_mask_out)
             return launch_conv_x6s_epi<G, PL, EPI_REF_IN>(a, n, st);
-        MMLF_CONV_KIND_SWITCH(launch_conv_x6s_epi, G == 18, G != 18 || a.seg_delta == 0, G, PL);
+        MMLF_CONV_KIND_SWITCH(launch_conv_x6s_epi, G == 18, G != 18 || a.seg_delta == 0 || conv_tr_any_shape(), G, PL);
     }
     // (other widths: the generic build, whose mask words have conv_epilogue16's layout for producer and consumer alike)
     return launch_conv_x6s_epi<G, PL, EPI_GENERIC>(a, ntiles, st);

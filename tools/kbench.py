@@ -19,6 +19,7 @@ def amax_for(t, cs):
     return geo.amax_of(t, cs) if NEW else t.abs().max().reshape(1)
 
 
+ZEROS = float(os.environ['KBENCH_ZEROS']) if os.environ.get('KBENCH_ZEROS') else None
 STAMPS = []      # KBENCH_STAMP=1: wall-clock windows of every timed loop (tools/power_kernels.sh aligns rocm-smi samples with them)
 
 
@@ -44,7 +45,12 @@ def grid_rand(cs, c, h, w, off, relu=False):
     v = t[:geo.NQ * cs].view(B, geo.R, geo.P, cs)
     v.zero_()
     r = torch.randn((B, h, w, c), device=dev)
-    v[:, off:off + h, off:off + w, :c] = r.clamp_(min=0) if relu else r
+    if ZEROS is not None:           # KBENCH_ZEROS=p: a fraction p of every operand tensor is exact zeros (matrix-core power is data dependent)
+        r = r.abs_() if relu else r
+        r[torch.rand_like(r) < ZEROS] = 0
+    elif relu:
+        r = r.clamp_(min=0)
+    v[:, off:off + h, off:off + w, :c] = r
     t.absmax = amax_for(t, cs)
     return t
 
