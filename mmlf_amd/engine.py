@@ -254,17 +254,18 @@ CHECK_ABSMAX = bool(os.environ.get('MMLF_CHECK_ABSMAX'))
 BATCHED = os.environ.get('MMLF_BATCHED', '1') != '0'
 # one BatchNorm-apply pass for the four streams' last blocks (whole rows of the concat buffer); 0: four slice passes
 APPLY4 = os.environ.get('MMLF_APPLY4', '1') != '0'
-# MMLF_OVERLAP_WGRAD (default 0): 1 = conv1's weight gradient of the wide blocks runs on a side stream beside the
-# BatchNorm-backward kernels of the block underneath (which only need the data gradient); 2 = both weight gradients of a
-# wide block on the side stream (measured 4.5 % SLOWER: two matrix-core kernels time-slice the CUs).
-# History of mode 1: +2 % in round 2, +-0 in round 3 (a weight-gradient workgroup then took 480 of a SIMD's 512 registers, so
+# MMLF_OVERLAP_WGRAD=1 (default 0): conv1's weight gradient of the wide blocks runs on a side stream beside the
+# BatchNorm-backward kernels of the block underneath (which only need the data gradient).  (Round 5 also queued BOTH weight
+# gradients of a block on the side stream, the main stream never waiting inside a block: 4.5 % SLOWER -- two matrix-core kernels
+# time-slice the CUs, the data gradients beside them ran 10.9 ms instead of 7.4; removed again, profiles/r05_overlap_modes.log.)
+# History: +2 % in round 2, +-0 in round 3 (a weight-gradient workgroup then took 480 of a SIMD's 512 registers, so
 # the BatchNorm workgroups could not share its CU and the kernels time-sliced), +0.9...1.1 % in round 5 on two boxes
 # (profiles/r05_overlap_modes.log): the kernel is down to 2 x 232 registers per SIMD and both BatchNorm-backward kernels fit
 # the 48 left (bn_reduce_bwd_kernel: 62 -> 48).  The side-stream launch then takes 11.3 ms instead of 7.6 (it shares the
 # CUs) while 4.7 ms of BatchNorm kernels hide behind it, the main-stream weight gradients run 3 % slower, and 5.5 GiB more
 # stay alive.  Left off: the gain is inside the box-to-box spread, and with it on the events around a weight gradient no
 # longer time the kernel alone (bench.py's roofline_wgrad).
-OVERLAP_WGRAD = int(os.environ.get('MMLF_OVERLAP_WGRAD', '0') or 0)
+OVERLAP_WGRAD = os.environ.get('MMLF_OVERLAP_WGRAD', '0') not in ('', '0')
 
 
 THIN_MAX_N, THIN_MIN_K = 2, 64     # mmlf_conv2x2_thin: at most 2 output channels over at least 64 input channels
@@ -574,17 +575,14 @@ class Trunk:
         if after_bn:
             after_bn()
         w1, w2 = p[f'{pre}.0.weight'], p[f'{pre}.2.weight']
-        both = overlap == 2 and need_dx      # both weight gradients go to the side stream, behind the data gradients
         # conv2 (pad 0): weight/bias gradient, then data gradient fused with the ReLU mask of y
-        if not both:
-            wgrad(geo, y, cs_mid, C, dz, cs_mid, C, P + 1, grads[f'{pre}.2.weight'], grads[f'{pre}.2.bias'], var,
-                  ws.wgrad_ws(geo, C, C))
+        wgrad(geo, y, cs_mid, C, dz, cs_mid, C, P + 1, grads[f'{pre}.2.weight'], grads[f'{pre}.2.bias'], var,
+              ws.wgrad_ws(geo, C, C))
         pk = packed(f'{pre}.2.weight', w2)
         if rec.get('ymask') is not None and CONV_MODE == 'f16x3':
             conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, mask_in=rec['ymask'])
         else:
             conv(geo, dz, cs_mid, C, pk, None, C, dy, cs_mid, 0, H + 1, W + 1, False, ref=y, cs_ref=cs_mid)
-        keep = (x, dy, y, dz) if both else (x, dy)
         del dz, got
         # conv1 (pad 1)
         if overlap and need_dx:
@@ -594,15 +592,12 @@ class Trunk:
             ready = main.record_event()
             with torch.cuda.stream(ws.side):
                 ws.side.wait_event(ready)
-                if both:
-                    wgrad(geo, y, cs_mid, C, keep[3], cs_mid, C, P + 1, grads[f'{pre}.2.weight'], grads[f'{pre}.2.bias'],
-                          var, ws.wgrad_ws(geo, C, C, side=True), side=True)
                 wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'],
                       var, ws.wgrad_ws(geo, spec.cin, C, side=True), side=True)
                 done = ws.side.record_event()
-            # the tensors the side stream reads: the caller keeps them alive until the main stream has waited
+            # x and dy are read by the side stream: the caller keeps them alive until the main stream has waited
             # for `done` (no record_stream: deferred reuse makes the caching allocator grow and stall)
-            return dx, done, keep
+            return dx, done, (x, dy)
         wgrad(geo, x, cs_x, spec.cin, dy, cs_mid, C, 0, grads[f'{pre}.0.weight'], grads[f'{pre}.0.bias'], var,
               ws.wgrad_ws(geo, spec.cin, C))
         if not need_dx:
@@ -626,29 +621,25 @@ class Trunk:
         cs_g = cs
         recs = tape['out']
         main = torch.cuda.current_stream()
-        pending = []                        # (event, prefix, tensors) of weight gradients still running on the side stream
+        pending = None                      # (event, prefix, tensors) of a weight gradient still running on the side stream
 
-        def settle(leave=0):
-            while len(pending) > leave:
-                ev, prefix, _ = pending.pop(0)      # (drops the tensors the side stream was reading)
-                main.wait_event(ev)
+        def settle():
+            nonlocal pending
+            if pending is not None:
+                main.wait_event(pending[0])
                 if on_done:
-                    on_done(prefix)
+                    on_done(pending[1])
+                pending = None              # drops the tensors the side stream was reading
 
-        # 1: the main stream takes a block's side-stream gradient back before its own next weight gradient;
-        # 2: no weight gradient of a wide block is on the main stream, which only waits for the block before the last
-        leave = 1 if OVERLAP_WGRAD == 2 else 0
         while recs:
             rec = recs.pop()
-            wide = OVERLAP_WGRAD if rec['spec'].cin >= 128 else 0
-            res = self._block_bwd(geo, rec, p, grads, g, cs_g, 0, True, after_bn=(lambda: settle(leave)), overlap=wide,
-                                  packs=tape.get('packs'))
-            settle(leave)                   # (blocks without BatchNorm never called it)
+            wide = OVERLAP_WGRAD and rec['spec'].cin >= 128
+            res = self._block_bwd(geo, rec, p, grads, g, cs_g, 0, True, after_bn=settle, overlap=wide, packs=tape.get('packs'))
+            settle()                        # (blocks without BatchNorm never called it)
             if wide:
                 g, ev, keep = res
-                pending.append((ev, rec['spec'].prefix, keep))
+                pending = (ev, rec['spec'].prefix, keep)
             else:
-                settle()                    # on_done keeps the order in which the gradient buckets complete
                 g = res
                 if on_done:
                     on_done(rec['spec'].prefix)
@@ -656,8 +647,8 @@ class Trunk:
         # g is now the gradient w.r.t. the concat buffer (cs = 4*chs); streams read channel slices
         for s in reversed(range(4)):
             recs = tape['streams'][s]
-            if s == 2 or (s == 3 and OVERLAP_WGRAD != 1):
-                settle()                    # (1: out_net.0's weight gradient ran beside the first stream's BatchNorm kernels)
+            if s == 2:
+                settle()                    # out_net.0's weight gradient ran beside the first stream's BatchNorm kernels
             gs, cs_s, off = g, cs_g, s * self.chs
             while recs:
                 rec = recs.pop()

@@ -431,8 +431,8 @@ def test_f16_split_is_scale_invariant(scale, monkeypatch):
 
 
 def test_side_stream_weight_gradient_gives_the_same_bits(monkeypatch):
-    """MMLF_OVERLAP_WGRAD=1 runs the wide blocks' first weight gradient on a side stream with its own workspace, =2 both
-    of them (beside the BatchNorm-backward kernels of the block underneath): the gradients must be bit-identical to the
+    """MMLF_OVERLAP_WGRAD=1 (off by default) runs the wide blocks' first weight gradient on a side stream with its own
+    workspace, beside the BatchNorm-backward kernels of the block underneath: the gradients must be bit-identical to the
     single-stream order, step after step."""
     from mmlf_amd import engine
     from mmlf_amd.train import TrainStep
@@ -441,13 +441,12 @@ def test_side_stream_weight_gradient_gives_the_same_bits(monkeypatch):
     dev = _dev()
     t = [torch.from_numpy(s).to(dev) for s in stacks]
     res = {}
-    for overlap in (0, 1, 2):
+    for overlap in (False, True):
         monkeypatch.setattr(engine, 'OVERLAP_WGRAD', overlap)
         step = TrainStep(_model(BASE_KW, state), lr=1e-3)
         for it in range(3):
             step(*t, torch.from_numpy(gt).to(dev), torch.from_numpy(mask).to(dev), it + 1)
         torch.cuda.synchronize()
         res[overlap] = (step.grad.clone(), step.flat.clone())
-    for overlap in (1, 2):
-        assert torch.equal(res[0][0], res[overlap][0]) and torch.equal(res[0][1], res[overlap][1]), overlap
-        assert torch.isfinite(res[overlap][0]).all() and float(res[overlap][0].abs().max()) > 0
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+    assert torch.isfinite(res[True][0]).all() and float(res[True][0].abs().max()) > 0
