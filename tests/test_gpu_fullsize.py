@@ -121,7 +121,9 @@ class _ChunkedConv(torch.autograd.Function):
     FULL-BATCH weight gradient is wrong at this size on this stack: for one 280->280 layer on a (512, 280, 96, 96) input
     (5.3 GB) `torch` (2.10.0+rocm7.0, MIOpen) returns a weight gradient 99.5 % (relative L2) away from the sum of its own four
     128-sample chunks, while this library's kernels agree with that sum to 1e-5 (tools/miopen_wgrad_bs512.py,
-    profiles/r04_miopen_wgrad_bs512.log).  The reference never meets this: its DataParallel puts 64 patches on a GPU."""
+    profiles/r04_miopen_wgrad_bs512.log).  The reference never meets this: its DataParallel puts 64 patches on a GPU.
+    This helper and _torch_forward_checkpointed are held against plain autograd of the same module, in float64 on the CPU with
+    chunks that do not divide the batch, by tests/test_fullsize_reference_cpu.py."""
     CH = 128
 
     @staticmethod
