@@ -58,6 +58,31 @@ def pmc_traffic(kernel, min_ns=3e6, max_ns=1e12):
     return None, f'unavailable: {why}'
 
 
+def kernel_sources_of(build):
+    """the part of an mmlf_build_info() string that identifies the kernels: the content hash of their sources (src=) and
+    every build switch -- not git=, which names the commit the library happened to be built at (a documentation commit
+    changes it, a kernel edit in a dirty tree does not)"""
+    return ' '.join(sorted(f for f in build.split() if not f.startswith('git=')))
+
+
+def pmc_build(loaded_build):
+    """(build string the committed PMC passes were collected on, or None for summaries older than round 6; whether it is the
+    library this run times).  The counters are a committed measurement, not a live one: when the kernels have changed since, the
+    over-fetch they report may no longer be the timed library's -- the line says which build they belong to and stderr warns."""
+    path = PMC_SUMMARY if os.path.isabs(PMC_SUMMARY) else os.path.join(ROOT, PMC_SUMMARY)
+    try:
+        with open(path) as f:
+            meta = json.load(f).get('_meta') or {}
+    except (OSError, ValueError):
+        meta = {}
+    b = meta.get('build')
+    same = b is not None and kernel_sources_of(b) == kernel_sources_of(loaded_build)
+    if not same:
+        print(f'bench.py: WARNING roofline.traffic comes from {PMC_SUMMARY}, collected on build [{b}]; the library timed here is '
+              f'[{loaded_build}] -- re-run tools/profile_round.sh if the kernels changed', file=sys.stderr, flush=True)
+    return b, same
+
+
 def host_threads():
     """threads this process may actually use (the GPU box gives a 1-GPU job a share of the host's cores)"""
     n = os.cpu_count() or 1
@@ -106,6 +131,38 @@ def cpu_baseline(variant, patch):
                       f'1 warm-up + 3 timed steps, median {med:.2f} s/step'}
 
 
+def workload_name(variant, world, global_batch, patch):
+    """config.workload: what was actually run, and which BASELINE.json config that is (configs[1] = BASE bs=512 on one GPU,
+    [2] = UPR bs=512 on one GPU, [3] = DPP bs=512 over 8 GPUs; anything else is named as the shape it is)"""
+    what = (f'{variant.upper()} fwd+bwd+Adam, global bs={global_batch} ps={patch} synthetic EPI patches, default torch init, '
+            f'{world} GPU' + ('s, data parallel' if world > 1 else ''))
+    std = global_batch == 512 and patch == 96
+    if std and world == 1 and variant in ('base', 'upr'):
+        return what + f' (BASELINE.json configs[{1 if variant == "base" else 2}])'
+    if std and variant == 'dpp':
+        return what + (' (BASELINE.json configs[3])' if world == 8 else f' (BASELINE.json configs[3] is this on 8 GPUs; this run: {world})')
+    if std:
+        return what + f' (the workload of BASELINE.json configs[{1 if variant == "base" else 2}] sharded over {world} GPUs)'
+    return what + ' (not a BASELINE.json shape)'
+
+
+def timed_steps(step, data, steps, first_it, sync):
+    """`steps` optimisation steps between two sync()s.  Returns (seconds, last loss, host_enqueue_ms): the last is the mean
+    wall time from a step's start until step() RETURNS (everything enqueued, nothing waited for) -- if that is not well under
+    the step's GPU time the rank is launch-bound (at 64 patches per rank a step is ~58 ms of GPU work behind ~1 000 launches
+    from Python / ctypes)."""
+    stacks, gt, mask = data
+    sync()
+    host = 0.0
+    t0 = time.time()
+    for k in range(steps):
+        h0 = time.time()
+        loss = step(*stacks, gt, mask, first_it + k)
+        host += time.time() - h0
+    sync()
+    return time.time() - t0, loss, 1e3 * host / max(1, steps)
+
+
 def make_step(variant, B, patch, dev, seed):
     from mmlf_amd.feed_forward import FeedForward
     from mmlf_amd.train import TrainStep
@@ -124,17 +181,47 @@ def extra_leg(variant, B, patch, dev, steps, peak):
     """one more BASELINE.json config through the same train step, single GPU: value + whole-step TFLOP/s"""
     step, stacks, gt, mask = make_step(variant, B, patch, dev, seed=1)
     step(*stacks, gt, mask, 1)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for it in range(steps):
-        loss = step(*stacks, gt, mask, 2 + it)
-    torch.cuda.synchronize()
-    dt = time.time() - t0
+    dt, loss, host_ms = timed_steps(step, (stacks, gt, mask), steps, 2, torch.cuda.synchronize)
     value = B * steps / dt
     tf = value * GFLOP_PER_PATCH[variant] * (patch / 96.0) ** 2 / 1e3
     out = {'value': round(value, 2), 'unit': 'patches/s', 'steps': steps, 'per_gpu_batch': B,
            'ms_per_step': round(1e3 * dt / steps, 2), 'whole_step_tflops': round(tf, 1),
-           'frac_of_peak': round(tf / peak, 4), 'loss': round(float(loss), 6)}
+           'frac_of_peak': round(tf / peak, 4), 'loss': round(float(loss), 6), 'host_enqueue_ms': round(host_ms, 2)}
+    del step, stacks, gt, mask
+    torch.cuda.empty_cache()
+    return out
+
+
+def allreduce_report(step, dev):
+    """per step, max over ranks: how long the compute stream stood behind each bucket's all-reduce after backward had been
+    enqueued (one entry per bucket, in firing order = backward order), and their sum"""
+    if step.buckets is None or not step.buckets.wait_events:
+        return None, None
+    ev = step.buckets.wait_events
+    per = torch.tensor([sum(s[b][0].elapsed_time(s[b][1]) for s in ev) / len(ev) for b in range(len(ev[0]))],
+                       dtype=torch.float64, device=dev)
+    tot = per.sum().reshape(1)
+    dist.all_reduce(per, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+    return round(float(tot), 3), [round(float(v), 3) for v in per]
+
+
+def ddp_leg(variant, global_batch, patch, dev, steps, world, rank, sync):
+    """another variant through the SAME N-rank path as the main leg (sharded batch, bucketed all-reduce, max-over-ranks time):
+    BASELINE.json configs[3] is the DPP net under data parallelism"""
+    B = global_batch // world
+    step, stacks, gt, mask = make_step(variant, B, patch, dev, seed=rank)
+    step(*stacks, gt, mask, 1)
+    step.buckets.wait_events = []
+    dt, loss, host_ms = timed_steps(step, (stacks, gt, mask), steps, 2, sync)
+    t = torch.tensor([dt, host_ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt, host_ms = float(t[0]), float(t[1])
+    ar_total, ar_buckets = allreduce_report(step, dev)
+    out = {'value': round(global_batch * steps / dt, 2), 'unit': 'patches/s', 'steps': steps, 'per_gpu_batch': B,
+           'ms_per_step': round(1e3 * dt / steps, 2), 'loss': round(float(loss), 6), 'host_enqueue_ms': round(host_ms, 2),
+           'allreduce_ms': ar_total, 'allreduce_ms_by_bucket': ar_buckets, 'buckets': len(step.buckets.ranges),
+           'gradient_bytes': int(step.grad.numel()) * 4, 'workload': workload_name(variant, world, global_batch, patch)}
     del step, stacks, gt, mask
     torch.cuda.empty_cache()
     return out
@@ -261,12 +348,8 @@ def main():
     engine.PROFILE = []           # (tag, flops, start_event, end_event) of the 280-wide conv / weight-gradient launches
     if step.buckets is not None:
         step.buckets.wait_events = []
-    t0 = time.time()
-    for _ in range(args.steps):
-        loss = step(*stacks, gt, mask, it)
-        it += 1
-    sync()
-    dt = time.time() - t0
+    dt, loss, host_ms = timed_steps(step, (stacks, gt, mask), args.steps, it, sync)      # sync: barrier + torch.cuda.synchronize()
+    it += args.steps
     prof, engine.PROFILE = engine.PROFILE, None
     peak_gib = torch.cuda.max_memory_allocated(dev) / 2.0 ** 30        # this rank's peak of live tensors over warm-up + timed steps
     # further legs (N=1 only): the same step in the two arithmetic modes that carry no precision asterisk -- the exact-f32
@@ -299,31 +382,30 @@ def main():
                            else 'conv4tap_x6s_kernel<18, 3, EPI> (v_mfma_f32_16x16x32_bf16, six cross terms)'),
                 'achieved': round(a1, 2), 'peak': round(pk, 1), 'frac': round(a1 / pk, 4),
                 'launches': len(p1), 'avg_ms': round(1e3 * s1 / max(1, len(p1)), 3)}
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, host_ms], dtype=torch.float64, device=dev)
     tmin = tmax.clone()
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)       # a slow rank shows as max well above min
-    dt, dt_min = float(tmax), float(tmin)
+    dt, dt_min, host_ms = float(tmax[0]), float(tmin[0]), float(tmax[1])
     loss_val = float(loss)
 
     n_buckets = len(step.buckets.ranges) if step.buckets is not None else 0
     grad_bytes = int(step.grad.numel()) * 4
-    allreduce_ms = None
-    if step.buckets is not None and step.buckets.wait_events:
-        # per step: how long the compute stream stood behind the bucket all-reduces after backward had been enqueued
-        ar = torch.tensor([sum(a.elapsed_time(b) for a, b in step.buckets.wait_events) / len(step.buckets.wait_events)],
-                          dtype=torch.float64, device=dev)
-        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
-        allreduce_ms = float(ar)
+    allreduce_ms, allreduce_by_bucket = allreduce_report(step, dev) if world > 1 else (None, None)
     # BASELINE.json configs[4] under --gpus N: replicas only -- every rank runs its own 512x512 light field
     # through the 70-member Ensamble, no collective on the data path; reported as max-over-ranks seconds per scene
     ese_rep = None
+    ddp_legs = {}
     if world > 1 and not args.no_extra_legs:
         passes_ = {'f16x3': 3, 'bf16x6': 6}.get(engine.CONV_MODE)
         peak_ = PEAK_BF16_MFMA_TFLOPS / passes_ if passes_ else PEAK_F32_MFMA_TFLOPS
         del step, stacks, gt, mask
         torch.cuda.empty_cache()
+        sync()
+        for v in ('dpp', 'upr'):              # the other variants under the same data parallelism (configs[3] = DPP x 8 GPUs)
+            if v != args.variant:
+                ddp_legs[v] = ddp_leg(v, args.global_batch, args.patch, dev, 2, world, rank, sync)
         sync()
         mine = ese_leg(dev, peak_, size=args.ese_size, seed=2 + rank)
         worst = torch.tensor([mine['value']], dtype=torch.float64, device=dev)
@@ -350,19 +432,21 @@ def main():
                           'passes, f32 accumulate)',
                  'bf16x6': 'f32 via exact 3 x bf16 operand split (6 MFMA passes, f32 accumulate)'}.get(engine.CONV_MODE, 'f32')
         traffic = pmc_traffic(kname) if args.global_batch == 512 and world == 1 else (None, 'n/a: not the bs=512 single-GPU shape')
+        traffic_build, traffic_same = pmc_build(_lib.build_info()) if traffic[0] else (None, None)
         line = {
             'metric': '96x96 EPI patches/sec fwd+bwd, bs=512', 'value': round(value, 3), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': dtype, 'data': 'synthetic',
-            'config': {'workload': f'{args.variant.upper()} fwd+bwd+Adam, global bs={args.global_batch} ps={args.patch} '
-                                   f'synthetic EPI patches, default torch init (BASELINE.json configs[1])',
+            'config': {'workload': workload_name(args.variant, world, args.global_batch, args.patch),
                        'per_gpu_batch': B, 'parallelism': f'dp{world}', 'loss': round(loss_val, 6)},
+            'host_enqueue_ms': round(host_ms, 2),
             'whole_step_tflops': round(value * GFLOP_PER_PATCH[args.variant] / 1e3, 2),
             'peak_hbm_gib': round(peak_gib, 1),
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(peak, 1),
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'traffic': traffic[0], 'traffic_source': traffic[1],
+                         'traffic_build': traffic_build, 'traffic_build_is_timed_build': traffic_same,
                          'kernel': kname + (', EPI> (280->280 forward + data-gradient launches, all epilogue variants)' if split
                                             else ' (280->280 forward + data-gradient launches)'),
                          'peak_is': (f'dense 16-bit MFMA 2500 TFLOP/s / {passes} passes per f32 product' if split
@@ -422,9 +506,15 @@ def main():
             line['config']['gradient_bytes'] = grad_bytes
             if ese_rep is not None:
                 line['ese_replicas'] = ese_rep
-            line['allreduce_ms'] = None if allreduce_ms is None else round(allreduce_ms, 3)
+            line['config']['buckets_note'] = 'default 3 is provisional: chosen on a gloo rehearsal, not on xGMI (MMLF_GRAD_BUCKETS)'
+            line['allreduce_ms'] = allreduce_ms
+            line['allreduce_ms_by_bucket'] = allreduce_by_bucket
             line['allreduce_note'] = ('per step, max over ranks: time the compute stream waits for the bucket all-reduces '
-                                      'after backward is enqueued (0 = fully overlapped with backward)')
+                                      'after backward is enqueued (0 = fully overlapped with backward); by_bucket in firing order')
+            line['host_enqueue_note'] = ('host_enqueue_ms: wall time until step() returns, nothing waited for, max over ranks; '
+                                         'a rank is launch-bound when this approaches ms_per_step')
+            for v, leg in ddp_legs.items():
+                line[v] = leg
         if args.backend != 'nccl':
             line['config']['backend'] = args.backend + ' (rehearsal: not an xGMI measurement)'
         if 'f32' in mode_legs:

@@ -32,13 +32,28 @@ def source_revision():
         return 'unknown'          # (no git on the GPU box's snapshot: the library that travels there was built here)
 
 
+HASHED = SOURCES + ['common.h', 'conv_device.h', os.path.join('..', '..', 'include', 'mmlf_hip.h')]
+
+
+def source_hash():
+    """content hash of everything the kernels are compiled from: mmlf_build_info()'s `src=` field.  Unlike `git=` (the HEAD
+    the library happened to be built at: build.stale() looks at file times, not at HEAD) it names the kernel sources
+    themselves -- bench.py compares it between the library it times and the one the committed PMC passes were collected on."""
+    import hashlib
+    h = hashlib.sha1()
+    for d in HASHED:
+        with open(os.path.join(HERE, d), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
 def build(force=False, verbose=True, extra_flags=(), lib=None):
     """extra_flags / lib: another build of the same sources somewhere else (tests/test_gpu_bounds.py: -DMMLF_BOUNDS_DEBUG)"""
     if lib is None and not extra_flags and not force and not stale():
         return LIB
     lib = lib or LIB
     tag = '' if lib == LIB else '.' + os.path.basename(lib).replace('.so', '')
-    flags = [*FLAGS, f'-DMMLF_GIT_HASH="{source_revision()}"', *extra_flags]
+    flags = [*FLAGS, f'-DMMLF_GIT_HASH="{source_revision()}"', f'-DMMLF_SRC_HASH="{source_hash()}"', *extra_flags]
     objs, jobs = [], []
     for src in SOURCES:                 # the translation units are independent: compiled side by side
         obj = os.path.join(os.path.dirname(lib), src.replace('.hip', tag + '.o'))
@@ -58,4 +73,9 @@ def build(force=False, verbose=True, extra_flags=(), lib=None):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    if '--source-hash' in sys.argv:
+        print(source_hash())
+    elif '--source-revision' in sys.argv:
+        print(source_revision())
+    else:
+        build(force='--force' in sys.argv)

@@ -67,6 +67,9 @@ struct ConvArgs {
     int a_pieces, seg_slot, seg_delta;   // split kernel: A window geometry (see conv4tap_x6s_kernel): 32-position pieces,
     int a_per_seg, a_tail;               // ... pieces per segment, positions the last piece of a segment has to fetch
     int nw;                              // waves per workgroup the launch uses (8, or 16: 512-position tiles)
+    int a_blocked;                       // round-6 proxy (MMLF_PROXY_BLOCKED_A=1, tools/kbench_blocked.py): `in` is a CHUNK-BLOCKED
+                                         // copy [tile][chunk of 8 channels][position][8 channels] of the NHWC tensor: one chunk of
+                                         // a window is one contiguous run of whole 128-byte lines, each fetched once
     const float *in_amax;                // f16 split: amax array of `in` (common.h): per-wave power-of-two operand scales
     const float *w_unscale;              // f16 split: 1 / (power-of-two scale of packed column n), [NP]
     float *out_amax;                     // optional: amax array of `out` (tensor and grid-row maxima, atomic max)
@@ -617,7 +620,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             for (int r = 0; r < 4; ++r) acc[mb][nb][r] = 0.f;
 
     // DMA addressing: a piece = wave-uniform 64-bit base (SGPRs) + one shared per-lane byte offset
-    const unsigned voff_a = ((unsigned)(lane >> 1) * (unsigned)a.cs_in + 4u * (lane & 1)) * 4u;   // A pieces
+    // (chunk-blocked input, a.a_blocked: a piece is 32 positions x 32 bytes of ONE contiguous 1 KiB run -- lane l fetches bytes
+    //  [16 l, 16 l + 16); the tile's chunks are TILE x 32 bytes apart and slots >= TILE live in the next tile's block)
+    const bool blocked = (G == 5 && PL == 2) ? a.a_blocked != 0 : false;      // (the other widths: a compile-time false)
+    const unsigned voff_a = blocked ? (unsigned)lane * 16u
+                                    : ((unsigned)(lane >> 1) * (unsigned)a.cs_in + 4u * (lane & 1)) * 4u;   // A pieces
+    const unsigned a_chunk_stride = blocked ? (unsigned)TILE * 32u : 32u;
     const unsigned voff_b = (unsigned)lane * 16u;                      // B pieces: linear
     const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
     const char *in0 = reinterpret_cast<const char *>(a.in);
@@ -637,12 +645,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
         const int j = w + NW * k;
         const int seg = j >= a.a_per_seg, idx = j - seg * a.a_per_seg;   // two-segment mode: 320-slot segments
         const int slot = 320 * seg + 32 * idx;
-        a_src[k] = (unsigned)(slot + seg * a.seg_delta) * (unsigned)a.cs_in * 4u;
+        a_src[k] = blocked ? (unsigned)(slot < TILE ? slot : a.nchunk * TILE + slot - TILE) * 32u
+                               : (unsigned)(slot + seg * a.seg_delta) * (unsigned)a.cs_in * 4u;
         // bit 0 marks the last piece of a window (of a segment): only its first a_tail positions are ever read; the
         // other lanes re-fetch the last of those instead of positions nobody uses
         a_dst[k] = (unsigned)slot * 32u + (idx == a.a_per_seg - 1 ? 1u : 0u);
     }
-    const unsigned tail_lim = ((unsigned)(a.a_tail - 1) * (unsigned)a.cs_in + 4u) * 4u;
+    const unsigned tail_lim = blocked ? (unsigned)(a.a_tail - 1) * 32u + 16u
+                                      : ((unsigned)(a.a_tail - 1) * (unsigned)a.cs_in + 4u) * 4u;
     const unsigned b_src0 = 1024u * jb0, b_dst0 = (unsigned)(A_F4 + 64 * jb0) * 16u;
 
 #ifdef MMLF_BOUNDS_DEBUG      // the piece's last source byte against the buffer (the address is made scalar again for the asm)
@@ -664,7 +674,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 || G <= 6 ? 4 : 2)) void conv4ta
             const char *sb_;                                                                             \
             unsigned vo_, d_;                                                                            \
             if ((k) < nA) {                                                                              \
-                sb_ = in0 + (size_t)(tl) * tile_bytes + 32u * (c) + a_src[(k) < 3 ? (k) : 0];            \
+                sb_ = in0 + (size_t)(tl) * tile_bytes + a_chunk_stride * (c) + a_src[(k) < 3 ? (k) : 0]; \
                 d_ = a_dst[(k) < 3 ? (k) : 0];                                                           \
                 vo_ = min(voff_a, (d_ & 1u) ? tail_lim : 0xffffffffu);                                   \
                 d_ &= ~1u;                                                                               \
@@ -1554,6 +1564,11 @@ static int conv_split_impl(const char *who, int planes, const float *in, int cs_
         a.a_per_seg = 9; a.a_pieces = 18; a.seg_slot = 320; a.seg_delta = g.P - 320;
     }
     a.a_tail = (a.seg_delta ? 257 : g.P + tile + 1) - 32 * (a.a_per_seg - 1);
+    {   // round-6 proxy: the caller passes a chunk-blocked copy of the input (see ConvArgs::a_blocked); tiled 80-column kernel only
+        const char *e = getenv("MMLF_PROXY_BLOCKED_A");
+        a.a_blocked = (e && atoi(e) && planes == 2 && np == 80 && a.seg_delta == 0 && !conv_rs_shape(planes, np, a.nchunk, a.nw)) ? 1 : 0;
+        MMLF_CHECK_ARG(!(e && atoi(e)) || a.a_blocked, "%s: MMLF_PROXY_BLOCKED_A is set but this launch has no chunk-blocked form", who);
+    }
     const long long ntiles = g.NQpad / tile;
     hipStream_t st = (hipStream_t)stream;
     return planes == 3 ? launch_conv_split<3>(np, a, ntiles, st) : launch_conv_split<2>(np, a, ntiles, st);
@@ -1777,14 +1792,14 @@ extern "C" int mmlf_conv2x2_thin(const float *in, int cs_in, int K, const float 
 extern "C" int mmlf_build_is_ablation(void) { return (MMLF_ABL_TERMS != 3 || MMLF_ABL_WGRAD_STAGE != 0) ? 1 : 0; }
 extern "C" const char *mmlf_build_info(void)
 {
-    static char text[320];
+    static char text[448];
     static std::once_flag once;
     std::call_once(once, [] {
         snprintf(text, sizeof(text),
-                 "abi=%d git=%s MMLF_ABL_TERMS=%d MMLF_ABL_WGRAD_STAGE=%d MMLF_GRID_PAD_W=%d MMLF_GRID_PAD_H=%d MMLF_RING16=%d "
-                 "MMLF_WGRAD_EARLY=%d MMLF_BOUNDS_DEBUG=%d ablation=%d",
-                 MMLF_ABI_VERSION, MMLF_GIT_HASH, MMLF_ABL_TERMS, MMLF_ABL_WGRAD_STAGE, MMLF_GRID_PAD_W, MMLF_GRID_PAD_H,
-                 MMLF_RING16, MMLF_WGRAD_EARLY, MMLF_BOUNDS_DEBUG_VALUE, mmlf_build_is_ablation());
+                 "abi=%d git=%s src=%s MMLF_ABL_TERMS=%d MMLF_ABL_WGRAD_STAGE=%d MMLF_GRID_PAD_W=%d MMLF_GRID_PAD_H=%d MMLF_RING16=%d "
+                 "MMLF_WGRAD_EARLY=%d MMLF_WGRADN_CLAMP=%d MMLF_WGRAD_ZEROPAD=%d MMLF_BOUNDS_DEBUG=%d ablation=%d",
+                 MMLF_ABI_VERSION, MMLF_GIT_HASH, MMLF_SRC_HASH, MMLF_ABL_TERMS, MMLF_ABL_WGRAD_STAGE, MMLF_GRID_PAD_W, MMLF_GRID_PAD_H,
+                 MMLF_RING16, MMLF_WGRAD_EARLY, MMLF_WGRADN_CLAMP, MMLF_WGRAD_ZEROPAD, MMLF_BOUNDS_DEBUG_VALUE, mmlf_build_is_ablation());
     });
     return text;
 }

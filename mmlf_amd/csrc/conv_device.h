@@ -8,19 +8,29 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// wave-uniform descriptor of what is left of a buffer of `total` bytes behind byte offset `off` (32-bit num_records)
-// (off <= total by construction: every caller's offset is that of a position inside the grid.  Formed in 16-byte units so that
-// shift, minimum and shift back are 32-bit scalar instructions: a 64-bit ordered compare would land on the vector unit.)
+// wave-uniform descriptor of what is left of a buffer of `total` bytes behind byte offset `off` (32-bit num_records).
+// The remainder is rounded UP to 16 bytes (a buffer whose byte count is not a multiple of 16 -- n_store = 70 floats in a 72-float
+// row -- keeps its last elements; every grid buffer has P + 72 positions of slack behind it) and an offset past the end gives
+// ZERO records, not an unsigned wrap-around to "unbounded" (round 5's form rounded down and wrapped; harmless only because of
+// the slack).  Formed in 16-byte units so that shift, minimum and shift back are 32-bit scalar instructions; the sign clamp is
+// mask arithmetic (a 64-bit ordered compare would land on the vector unit).
+// In the product build an access past num_records is DROPPED (stores) or reads 0 (loads): a quietly wrong result instead of a
+// fault.  The signals that it does not happen: -DMMLF_BOUNDS_DEBUG counts every such access on the GPU (tests/test_gpu_bounds.py),
+// and MMLF_CHECK_EXTENTS=1 makes the host compare the audited end of every launch with the bytes behind each pointer it was
+// given (mmlf_amd/engine.py, tests/test_gpu_bounds.py::test_host_extent_check_*).
 __device__ __forceinline__ int mmlf_records_left(long long total, long long off)
 {
-    const unsigned left16 = (unsigned)((unsigned long long)(total - off) >> 4);
+    const long long left = total - off;
+    const unsigned long long pos = (unsigned long long)(left & ~(left >> 63));         // max(left, 0)
+    const unsigned left16 = (unsigned)((pos + 15) >> 4);
     return (int)((left16 < 0x7ffffffu ? left16 : 0x7ffffffu) << 4);
 }
 
 // Build switches.  Round 5 removed the timing-ablation switches of rounds 3-4 whose experiments are closed (their numbers
 // stay in EXPERIMENTS.md 4.7-4.8: half weight-fragment reads, double split, pre-split operand, 32x32x16 tiles, no early
 // barrier, non-temporal activation DMA, wave priorities, the narrow kernel's timeline; check out round 4's tree to rebuild
-// them).  What is left changes either nothing observable (MMLF_RING16, MMLF_WGRAD_EARLY: tuning constants) or the RESULT:
+// them).  What is left changes either nothing observable (MMLF_RING16, MMLF_WGRAD_EARLY, MMLF_WGRADN_CLAMP, MMLF_WGRAD_ZEROPAD:
+// tuning constants and equivalent forms) or the RESULT:
 //   MMLF_ABL_TERMS < 3 -- run only 2 or 1 of the f16 split's three cross terms (a timing ablation: WRONG results);
 //   MMLF_ABL_WGRAD_STAGE -- timing ablations of the wide weight gradient's staging (below: WRONG results).
 // mmlf_build_info() reports every one of them and the Python loader refuses a library with a result-changing switch
@@ -43,6 +53,15 @@ __device__ __forceinline__ int mmlf_records_left(long long total, long long off)
 // merges the two 64-byte halves of an output line that two store instructions write; the switch was removed again)
 #ifndef MMLF_WGRAD_EARLY
 #define MMLF_WGRAD_EARLY 1     // the wide weight gradient's early barrier + next-chunk fragment prefetch (16 VGPRs)
+#endif
+#ifndef MMLF_WGRADN_CLAMP
+#define MMLF_WGRADN_CLAMP 1    // narrow weight gradient: staging items and channels past the tile are clamped, not predicated (wgrad.hip)
+#endif
+#ifndef MMLF_WGRAD_ZEROPAD
+#define MMLF_WGRAD_ZEROPAD 0   // wide weight gradient: 1 = padding channels staged as zeros behind selects (round 4's form; wgrad.hip)
+#endif
+#ifndef MMLF_SRC_HASH
+#define MMLF_SRC_HASH "unknown"     // content hash of csrc/*.hip, csrc/*.h and include/mmlf_hip.h (csrc/build.py, tools/build_variant.sh)
 #endif
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 

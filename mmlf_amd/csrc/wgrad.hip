@@ -351,9 +351,6 @@ __global__ __launch_bounds__(256, 2) void wgrad4tap_x6n_kernel(WgradArgs a)
     // MMLF_WGRADN_CLAMP (round 5): staging items and channels past the tile are CLAMPED -- surplus threads load and store the last
     // item again, padding channels are copies of the tensor's last four -- instead of predicated and zero-filled: no divergent
     // branch per piece; the padding only feeds accumulator rows / columns the reduction never reads (as in the wide kernel).
-#ifndef MMLF_WGRADN_CLAMP
-#define MMLF_WGRADN_CLAMP 1
-#endif
     float4 ra[NA], rg[NG];
 #define WN_GLOAD(c)                                                                                         \
     do {                                                                                                    \
@@ -522,9 +519,6 @@ __global__ __launch_bounds__(512, 2) void wgrad4tap_x6w_kernel(WgradArgs a)
     // wgrad_reduce_kernel never reads (ci > Cin, co >= Cout), the copies are in-range values (no f16 overflow), and the ones row
     // (ci == Cin) is patched in WW_STORE_A either way.  Four selects per staging piece less (round 5;
     // -DMMLF_WGRAD_ZEROPAD=1 builds the zero-filling form: profiles/r05_kbench_wgrad_zeropad.log).
-#ifndef MMLF_WGRAD_ZEROPAD
-#define MMLF_WGRAD_ZEROPAD 0
-#endif
 
     // staging items are clamped to the last one instead of predicated: surplus threads load and store that
     // item again (same value), which keeps the loop free of branches.  Also of SCALAR ones: round 5 let the waves whose

@@ -254,18 +254,60 @@ CHECK_ABSMAX = bool(os.environ.get('MMLF_CHECK_ABSMAX'))
 BATCHED = os.environ.get('MMLF_BATCHED', '1') != '0'
 # one BatchNorm-apply pass for the four streams' last blocks (whole rows of the concat buffer); 0: four slice passes
 APPLY4 = os.environ.get('MMLF_APPLY4', '1') != '0'
-# MMLF_OVERLAP_WGRAD=1 (default 0): conv1's weight gradient of the wide blocks runs on a side stream beside the
-# BatchNorm-backward kernels of the block underneath (which only need the data gradient).  (Round 5 also queued BOTH weight
-# gradients of a block on the side stream, the main stream never waiting inside a block: 4.5 % SLOWER -- two matrix-core kernels
-# time-slice the CUs, the data gradients beside them ran 10.9 ms instead of 7.4; removed again, profiles/r05_overlap_modes.log.)
-# History: +2 % in round 2, +-0 in round 3 (a weight-gradient workgroup then took 480 of a SIMD's 512 registers, so
-# the BatchNorm workgroups could not share its CU and the kernels time-sliced), +0.9...1.1 % in round 5 on two boxes
-# (profiles/r05_overlap_modes.log): the kernel is down to 2 x 232 registers per SIMD and both BatchNorm-backward kernels fit
-# the 48 left (bn_reduce_bwd_kernel: 62 -> 48).  The side-stream launch then takes 11.3 ms instead of 7.6 (it shares the
-# CUs) while 4.7 ms of BatchNorm kernels hide behind it, the main-stream weight gradients run 3 % slower, and 5.5 GiB more
-# stay alive.  Left off: the gain is inside the box-to-box spread, and with it on the events around a weight gradient no
-# longer time the kernel alone (bench.py's roofline_wgrad).
-OVERLAP_WGRAD = os.environ.get('MMLF_OVERLAP_WGRAD', '0') not in ('', '0')
+# MMLF_OVERLAP_WGRAD (default 1 since round 6; 0 switches it off): conv1's weight gradient of the wide blocks runs on a side
+# stream beside the BatchNorm-backward kernels of the block underneath (which only need the data gradient).  It pays since the
+# weight gradient is down to 2 x 232 registers per SIMD and both BatchNorm-backward kernels fit the 48 left (round 5:
+# +0.9...1.1 % on two boxes, gradients bit-identical, profiles/r05_overlap_modes.log; round 6's same-box A/B:
+# profiles/r06_ab_overlap_wgrad.log).  The side-stream launch takes ~11.3 ms instead of 7.6 (it shares the CUs) while 4.7 ms of
+# BatchNorm kernels hide behind it; +5.5 GiB stay alive (x and dy of one block, until the main stream has waited for the launch).
+# The events around a side-stream launch do not time the kernel alone: bench.py's roofline_wgrad is taken on the main-stream
+# launches (conv2's gradients: same kernel, same shape).  History of the rejected forms: EXPERIMENTS.md 4.9.
+OVERLAP_WGRAD = os.environ.get('MMLF_OVERLAP_WGRAD', '1') not in ('', '0')
+
+
+# MMLF_CHECK_EXTENTS=1 (debug; the f16-split launches): before every convolution / weight-gradient launch the host compares
+# the audited END of what the launch may touch behind each pointer (mmlf_audit_conv_h2 / mmlf_audit_wgrad_h2: derived from the
+# launch geometry) with the bytes the tensor behind that pointer really has, and raises instead of launching.  The product
+# kernels' range-checked descriptors DROP a stray access (conv_device.h: mmlf_records_left), so a wrong extent would be a quietly
+# wrong result; this is the product-build signal for it (the -DMMLF_BOUNDS_DEBUG build counts accesses on the GPU instead).
+CHECK_EXTENTS = bool(os.environ.get('MMLF_CHECK_EXTENTS'))
+EXTENT_CHECKS = 0         # launches checked so far (tests)
+
+
+def _bytes_behind(t, off_floats=0):
+    """bytes from a tensor's first element (+ an offset) to the end of its storage"""
+    return t.untyped_storage().nbytes() - t.storage_offset() * t.element_size() - 4 * off_floats
+
+
+def _check_extents(kind, ends, have):
+    global EXTENT_CHECKS
+    for name, (end, t, off) in have.items():
+        if t is None:
+            continue
+        got = _bytes_behind(t, off)
+        if end > got:
+            raise RuntimeError(f'MMLF_CHECK_EXTENTS: {kind}: the launch may touch {end} bytes behind `{name}`, the tensor has {got}')
+    EXTENT_CHECKS += 1
+
+
+def _check_conv_extents(geo, x, cs_in, K, packed, bias, N, out, cs_out, n_store, out_off, out_shift, ref, cs_ref, ax, aout,
+                        bn_partial, mask_out, mask_in):
+    import ctypes
+    e = (ctypes.c_int64 * 9)()
+    call('mmlf_audit_conv_h2', cs_in, K, N, cs_out, n_store, out_shift, cs_ref, geo.B, geo.H, geo.W, e)
+    _check_extents(f'conv {K}->{N} B={geo.B} {geo.H}x{geo.W} shift={out_shift}', e,
+                   {'in': (e[0], x, 0), 'packed': (e[1], packed, 0), 'bias': (e[2], bias, 0), 'out': (e[3], out, out_off),
+                    'ref': (e[4], ref, 0), 'in_amax': (e[5], ax, 0), 'out_amax': (e[6], aout, 0),
+                    'bn_partial': (e[7], bn_partial, 0), 'mask_out': (e[8], mask_out, 0), 'mask_in': (e[8], mask_in, 0)})
+
+
+def _check_wgrad_extents(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, workspace, ax, ag):
+    import ctypes
+    e = (ctypes.c_int64 * 7)()
+    call('mmlf_audit_wgrad_h2', cs_in, cin, cs_g, cout, g_shift, geo.B, geo.H, geo.W, e)
+    _check_extents(f'wgrad {cin}->{cout} B={geo.B} {geo.H}x{geo.W} g_shift={g_shift}', e,
+                   {'in': (e[0], x, 0), 'g': (e[1], g, 0), 'gw': (e[2], gw, 0), 'gb': (e[3], gb, 0),
+                    'workspace': (e[4], workspace, 0), 'in_amax': (e[5], ax, 0), 'g_amax': (e[6], ag, 0)})
 
 
 THIN_MAX_N, THIN_MIN_K = 2, 64     # mmlf_conv2x2_thin: at most 2 output channels over at least 64 input channels
@@ -288,6 +330,8 @@ def wgrad(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, variant, workspace
         e0.record()
     if CONV_MODE == 'f16x3':
         ax, ag = _amax_of(geo, x, cs_in), _amax_of(geo, g, cs_g)
+        if CHECK_EXTENTS:
+            _check_wgrad_extents(geo, x, cs_in, cin, g, cs_g, cout, g_shift, gw, gb, workspace, ax, ag)
         call('mmlf_conv2x2_wgrad_h2', *args, ptr(ax), ptr(ag), _lib.stream_ptr())
     else:
         call('mmlf_conv2x2_wgrad_split' if CONV_MODE == 'bf16x6' else 'mmlf_conv2x2_wgrad', *args, _lib.stream_ptr())
@@ -322,6 +366,9 @@ def conv(geo, x, cs_in, K, packed, bias, N, out, cs_out, out_shift, vh, vw, relu
             cs_out if n_store is None else n_store, out_shift, vh, vw, geo.B, geo.H, geo.W, int(relu), ptr(ref), cs_ref)
     if CONV_MODE == 'f16x3':
         ax = _amax_of(geo, x, cs_in)
+        if CHECK_EXTENTS:
+            _check_conv_extents(geo, x, cs_in, K, packed, bias, N, out, cs_out, cs_out if n_store is None else n_store, out_off,
+                                out_shift, ref, cs_ref, ax, getattr(out, 'absmax', None), bn_partial, mask_out, mask_in)
         call('mmlf_conv2x2_h2', *args, ptr(ax), ptr(getattr(out, 'absmax', None)), ptr(bn_partial), ptr(mask_out),
              ptr(mask_in), _lib.stream_ptr())
     else:

@@ -147,7 +147,8 @@ class _HeadUprFn(torch.autograd.Function):
 class _HeadDppFn(torch.autograd.Function):
     """one_hot, posterior, mean, logvar of the DPP head (reference feed_forward.py:276-290): posterior and logvar are
     differentiable in the scores (mmlf_head_dpp_bwd); one_hot and the arg-max mean are constants of the graph, as in the
-    reference (a comparison has no gradient)."""
+    reference (a comparison has no gradient).  Where all posterior mass sits on the arg-max bin the variance is 0, logvar is
+    -inf and its gradient is inf / NaN -- in the reference's autograd graph (log at 0) as here; no floor is applied."""
 
     @staticmethod
     def forward(ctx, scores, grid_torch, grid_np, steps):
@@ -161,6 +162,9 @@ class _HeadDppFn(torch.autograd.Function):
         ctx.save_for_backward(sc, grid_np, mean)
         ctx.steps = steps
         ctx.mark_non_differentiable(one_hot, mean)
+        # an output nobody differentiates arrives as None in backward (not as a materialised zero tensor): the NULL-pointer
+        # paths of mmlf_head_dpp_bwd are real, and a graph that uses neither posterior nor logvar launches nothing
+        ctx.set_materialize_grads(False)
         return one_hot, posterior, mean, logvar
 
     @staticmethod

@@ -129,7 +129,7 @@ class GradBuckets:
         # runs of consecutive keys, as even in count as possible (the wide blocks are equal in bytes; the two stream nets
         # together are 5 % of the gradient and share the last run's tail)
         bounds = [round(i * len(self.keys) / n_buckets) for i in range(n_buckets + 1)]
-        self.ranges, self.trigger, self.bucket_of = {}, {}, {}
+        self.ranges, self.bucket_of = {}, {}
         for b in range(n_buckets):
             run = self.keys[bounds[b]:bounds[b + 1]]
             lo, hi = min(fine[k][0] for k in run), max(fine[k][1] for k in run)
@@ -139,7 +139,9 @@ class GradBuckets:
                 self.bucket_of[k] = run[-1]
         self.pending = []
         self.done = set()
-        self.wait_events = None      # bench.py: a list that receives (start, end) HIP events around each step's waits
+        # bench.py: a list that receives, per step, one (start, end) HIP event pair per bucket around that bucket's wait (in the
+        # order the buckets were fired: the time the compute stream stood behind each all-reduce after backward was enqueued)
+        self.wait_events = None
 
     def ready(self, flat_grad, key):
         """backward has enqueued every gradient of `key`: fire its bucket if that completes the bucket's run"""
@@ -160,14 +162,17 @@ class GradBuckets:
             if last not in self.done:
                 self._fire(flat_grad, last)
         timed = self.wait_events is not None and flat_grad.is_cuda
-        if timed:       # how long the compute stream stands behind the collectives once backward is through
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        for w in self.pending:
+        pairs = []
+        for w in self.pending:      # how long the compute stream stands behind each collective once backward is through
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             w.wait()
+            if timed:
+                e1.record()
+                pairs.append((e0, e1))
         if timed:
-            e1.record()
-            self.wait_events.append((e0, e1))
+            self.wait_events.append(pairs)
         self.pending, self.done = [], set()
 
 
@@ -195,7 +200,7 @@ class TrainStep:
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
-        self.buckets = GradBuckets(self.layout, process_group) if self.distributed else None
+        self.buckets = GradBuckets(self.layout, process_group, self._agreed_bucket_count()) if self.distributed else None
         self._grads = {name: self.grad[o:o + n].view_as(dict(model.named_parameters())[name])
                        for name, o, n in self.layout}
         self._margin_mask = {}
@@ -204,6 +209,21 @@ class TrainStep:
             self.sync_buffers()
 
     # ------------------------------------------------------------------ pieces
+    def _agreed_bucket_count(self):
+        """MMLF_GRAD_BUCKETS is read per process: ranks that disagreed would issue different numbers and sizes of
+        all-reduces (a hang, or gradients summed into the wrong slices).  Rank 0's value is used by everyone, and a rank
+        whose own environment said something else says so once."""
+        if not self.distributed:
+            return None
+        mine = bucket_count()
+        n = torch.tensor([mine], dtype=torch.int64, device=self.flat.device)
+        dist.broadcast(n, 0, group=self.group)
+        n = int(n)
+        if n != mine:
+            import warnings
+            warnings.warn(f'MMLF_GRAD_BUCKETS: this rank has {mine}, rank 0 has {n}; using rank 0\'s')
+        return n
+
     def sync_buffers(self):
         """BatchNorm buffers of rank 0 win (DataParallel keeps GPU0's running statistics)."""
         if self.distributed:
@@ -231,11 +251,22 @@ class TrainStep:
         inds = torch.max(mpi[:, :, 3, :, :], dim=1)[1].unsqueeze(1)
         return torch.gather(mpi[:, :, 4, :, :], dim=1, index=inds).squeeze(1)
 
-    def _den_override(self, mask):
+    def _den_begin(self, mask):
+        """The loss denominator under data parallelism is the GLOBAL count of valid pixels / world size (the reference
+        evaluates the loss on the gathered batch, train/cli.py:245-255).  The count's all-reduce is ISSUED here, in front
+        of the forward pass, and waited for by `_den_end` in front of the loss kernel (which reads the denominator from a
+        device scalar): no rank stands at a rendezvous before its first kernel -- until round 5 this was a blocking
+        all-reduce ahead of forward."""
         if not self.distributed:
             return None
         cnt = mask.sum().double().reshape(1)
-        dist.all_reduce(cnt, group=self.group)
+        return cnt, dist.all_reduce(cnt, group=self.group, async_op=True)
+
+    def _den_end(self, started):
+        if not isinstance(started, tuple):      # None, or a denominator the caller already holds (tests)
+            return started
+        cnt, work = started
+        work.wait()                 # (a stream dependency for RCCL; host-blocking for gloo)
         return cnt / self.world
 
     # ------------------------------------------------------------------ the step
@@ -250,7 +281,7 @@ class TrainStep:
         if self.strongest:
             gt = self.strongest_gt(gt).contiguous()
         mask = self._mask(mask)
-        den = self._den_override(mask)
+        den = self._den_begin(mask)
         self.grad.zero_()
         if h.is_cuda and model._native_ok:
             loss = self._native_fwd_bwd(h, v, i_, d, gt, mask, den)
@@ -267,6 +298,7 @@ class TrainStep:
         p = model._tensor_dict()
         with torch.no_grad():
             out, tape = model._trunk.forward(p, [h, v, i_, d], model.training, True)
+            den = self._den_end(den)
             if self.multimodal:
                 loss, gout = self._multimodal_loss(out, gt, mask, den)
             else:
@@ -340,6 +372,7 @@ class TrainStep:
         for _, p in model.named_parameters():
             p.grad = None
         out = model(h, v, i_, d)
+        den = self._den_end(den)
         if self.multimodal:
             loss = self._multimodal_heads_loss(out, gt, mask)
         elif self.variant == 'upr':

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import TINY_KW
+from conftest import TINY_KW, VARIANTS
 from mmlf_amd import synth
 from mmlf_amd.feed_forward import FeedForward
 from mmlf_amd.train import GradBuckets, TrainStep, flatten_parameters
@@ -38,13 +38,20 @@ def _data(world=2):
     return [torch.from_numpy(s) for s in stacks], torch.from_numpy(gt), torch.from_numpy(mask)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, variant_kw=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.set_num_threads(2)
+    if os.environ.get('TEST_BUCKETS_DISAGREE') and rank == 1:
+        os.environ['MMLF_GRAD_BUCKETS'] = '1'           # rank 0's value must win (TrainStep._agreed_bucket_count)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        model = _make(seed=3 + rank)          # different weights per rank: the broadcast must fix that
-        step = TrainStep(model, lr=1e-2, loss_margin=3)
+        model = _make(seed=3 + rank, variant_kw=variant_kw)      # different weights per rank: the broadcast must fix that
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            step = TrainStep(model, lr=1e-2, loss_margin=3)
+        if os.environ.get('TEST_BUCKETS_DISAGREE'):
+            assert len(step.buckets.ranges) == 5, len(step.buckets.ranges)
         stacks, gt, mask = _data(world)
         lo, hi = 2 * rank, 2 * rank + 2
         losses = []
@@ -57,14 +64,24 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,buckets', [(2, None), (4, None), (2, '1'), (2, '10')])
-def test_n_rank_step_equals_manual_average(tmp_path, world, buckets, monkeypatch):
+@pytest.mark.parametrize('world,buckets,variant', [(2, None, 'base'), (4, None, 'base'), (2, '1', 'base'), (2, '10', 'base'),
+                                                   (2, None, 'dpp'), (2, '10', 'dpp'), (2, None, 'upr'), (2, 'disagree', 'base')])
+def test_n_rank_step_equals_manual_average(tmp_path, world, buckets, variant, monkeypatch):
     """buckets: MMLF_GRAD_BUCKETS -- the gradient carried by one all-reduce / one per block instead of the default three
-    (round 5: the knob the first 8-GPU run needs); the result must not depend on it"""
-    if buckets is not None:
+    (round 5: the knob the first 8-GPU run needs); the result must not depend on it.  'disagree': rank 1's environment
+    says 1, rank 0's 10 -- rank 0's count is used by both (round 6).
+    variant 'dpp' (round 6): BASELINE.json configs[3] is the discrete-posterior net UNDER data parallelism (reference
+    mmlf/train/cli.py:159 with :201-207,247-255): cross entropy on reg_to_class targets with the global masked-mean
+    denominator, the 108-channel head's gradient in the last bucket."""
+    if buckets == 'disagree':
+        monkeypatch.setenv('MMLF_GRAD_BUCKETS', '10')
+        monkeypatch.setenv('TEST_BUCKETS_DISAGREE', '1')
+    elif buckets is not None:
         monkeypatch.setenv('MMLF_GRAD_BUCKETS', buckets)      # (inherited by the spawned ranks)
+    vkw = VARIANTS[variant]
+    _make_v = lambda seed=3: _make(seed, vkw)
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), vkw), nprocs=world, join=True)
     ranks = [torch.load(tmp_path / f'r{r}.pt') for r in range(world)]
     r0, r1 = ranks[0], ranks[1]
     for rk in ranks[1:]:
@@ -75,7 +92,7 @@ def test_n_rank_step_equals_manual_average(tmp_path, world, buckets, monkeypatch
     # single-process emulation: `world` replicas with replica-local BN statistics, gradients averaged,
     # loss normalised by the GLOBAL mask count (reference computes the loss on the gathered batch)
     stacks, gt, mask = _data(world)
-    replicas = [_make(seed=3) for _ in range(world)]
+    replicas = [_make_v(3) for _ in range(world)]
     steps = [TrainStep(m, lr=1e-2, loss_margin=3) for m in replicas]
     margin = steps[0]._mask(mask)
     total = float(margin.sum())
@@ -97,20 +114,28 @@ def test_n_rank_step_equals_manual_average(tmp_path, world, buckets, monkeypatch
             np.testing.assert_allclose(rk['losses'][it - 1], want, rtol=1e-5)
     # Adam turns rounding noise on exactly-zero gradients (conv biases in front of a train-mode BN)
     # into +-lr steps, so only elements with a solid gradient are comparable; the rest is bounded.
-    torch.testing.assert_close(r0['flat'][solid], steps[0].flat[solid], rtol=1e-4, atol=2e-5)
+    # (dpp: elements whose gradient is rounding noise take +-lr steps in step 1 that are not shadowed by a BatchNorm, so step
+    # 2's gradients differ at the 1e-3 level here and there: 1 % of an lr step is the bar, the losses above are held to 1e-5)
+    torch.testing.assert_close(r0['flat'][solid], steps[0].flat[solid], rtol=1e-4, atol=1e-4 if variant == 'dpp' else 2e-5)
     assert float((r0['flat'] - steps[0].flat).abs().max()) <= 2 * 2 * 1e-2 + 1e-6
-    assert float(solid.float().mean()) > 0.9
+    # (dpp: most of the 108 x 108 head filter belongs to classes no target of four 16 x 16 patches hits)
+    assert float(solid.float().mean()) > (0.5 if variant == 'dpp' else 0.9)
     # the rank-averaged loss is the global masked mean
     np.testing.assert_allclose(sum(rk['losses'][0] for rk in ranks) / world,
-                               (_global_loss(_make(seed=3), stacks, gt, margin)), rtol=0.2)
+                               (_global_loss(_make_v(3), stacks, gt, margin, variant)), rtol=0.2)
 
 
-def _global_loss(model, stacks, gt, mask):
+def _global_loss(model, stacks, gt, mask, variant='base'):
     # loose sanity bound only: BN statistics differ between the sharded and the un-sharded forward
-    from mmlf_amd import loss
+    from mmlf_amd import dl, loss
     model.train()
     with torch.no_grad():
-        return float(loss.MaskedL1Loss()(model(*stacks), gt, mask))
+        out = model(*stacks)
+        if variant == 'dpp':
+            return float(loss.MaskedCrossEntropy()(out, dl.reg_to_class(gt, model.disp_min, model.disp_max, model.steps), mask))
+        if variant == 'upr':
+            return float(loss.ImprovedUncertaintyL1Loss()(out, gt, mask, None))
+        return float(loss.MaskedL1Loss()(out, gt, mask))
 
 
 def test_bucket_layout_covers_every_parameter_once():

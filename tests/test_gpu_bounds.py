@@ -29,3 +29,49 @@ def test_no_access_leaves_the_buffers_in_a_bounds_counting_build(tmp_path):
     for leg in ('kbench_280', 'kbench_70', 'train_base', 'train_dpp', 'eval_wide_frame'):
         assert all(v == 0 for v in report[leg].values()), (leg, report[leg])
     assert report['total'] == 0
+
+
+@pytest.mark.gpu
+def test_host_extent_check_passes_the_step_and_refuses_a_short_buffer(monkeypatch):
+    """MMLF_CHECK_EXTENTS (round 6): the product kernels' range-checked descriptors DROP a stray access instead of faulting,
+    so the product build needs a signal of its own -- the host holds the audited end of every convolution / weight-gradient
+    launch against the bytes really behind each pointer.  A DPP train step and a tiled evaluation pass run clean under it
+    (every launch checked), and a buffer without the prescribed slack is refused before anything is launched."""
+    import numpy as np
+    import torch
+    from conftest import TINY_KW
+    from mmlf_amd import engine, synth
+    from mmlf_amd.feed_forward import FeedForward
+    from mmlf_amd.train import TrainStep
+    monkeypatch.setattr(engine, 'CHECK_EXTENTS', True)
+    monkeypatch.setattr(engine, 'EXTENT_CHECKS', 0)
+    dev = torch.device('cuda:0')
+    kw = dict(TINY_KW, model_discrete=True)
+    model = FeedForward(**kw)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.synth_state(synth.param_spec(**kw), 2).items()})
+    model.to(dev)
+    stacks, gt, mask = synth.synth_inputs(3, 24, seed=4)
+    t = [torch.from_numpy(s).to(dev) for s in stacks]
+    step = TrainStep(model, lr=1e-3, loss_margin=3)
+    loss = step(*t, torch.from_numpy(gt).to(dev), torch.from_numpy(mask).to(dev), 1)
+    model.eval()
+    with torch.no_grad():
+        model(*t)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+    # 2 nets x 2 streams x 2 blocks + 3 out blocks = 11 blocks: 2 forward convs each in both passes, 2 data + 2 weight gradients
+    # (no data gradient into the images)
+    assert engine.EXTENT_CHECKS >= 11 * 2 * 2 + 11 * 2 + 7, engine.EXTENT_CHECKS
+    # a short input buffer: the image positions alone, without the tile padding and tap slack mmlf_grid_alloc_positions adds
+    geo = engine.Geometry(3, 24, 24)
+    cs = engine.cs_of(8)
+    x = geo.buf(cs, dev)
+    short = x[:geo.NQ * cs].clone()
+    short.absmax = x.absmax
+    out = geo.buf(cs, dev)
+    w = torch.randn(8, 8, 2, 2, device=dev)
+    pk = engine.pack_filter(w, 0, False)
+    with pytest.raises(RuntimeError, match='MMLF_CHECK_EXTENTS.*`in`'):
+        engine.conv(geo, short, cs, 8, pk, torch.zeros(8, device=dev), 8, out, cs, 0, 25, 25, True)
+    engine.conv(geo, x, cs, 8, pk, torch.zeros(8, device=dev), 8, out, cs, 0, 25, 25, True)       # the full one passes
+    torch.cuda.synchronize()

@@ -42,8 +42,10 @@ def test_upr_posterior_gradient_equals_autograd_of_the_reference_expression():
     assert float(err) <= 2e-5, float(err)
 
 
-@pytest.mark.parametrize('which', ['posterior', 'logvar', 'both'])
+@pytest.mark.parametrize('which', ['posterior', 'logvar', 'both', 'posterior_alone', 'logvar_alone'])
 def test_dpp_head_gradients_equal_autograd_of_the_reference_expressions(which):
+    """*_alone (round 6): the other output is not part of the graph at all, so its gradient arrives as None
+    (ctx.set_materialize_grads(False)) and mmlf_head_dpp_bwd runs with a NULL pointer for it"""
     from mmlf_amd.feed_forward import _HeadDppFn
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(5)
@@ -58,12 +60,17 @@ def test_dpp_head_gradients_equal_autograd_of_the_reference_expressions(which):
     post64 = e / torch.sum(e, 1, keepdim=True)
     mean64 = torch.sum(grid_t.double().view(1, -1, 1, 1) * one_hot, 1)
     lv64 = torch.log(torch.sum((grid_np.double().view(1, -1, 1, 1) - mean64.unsqueeze(1)) ** 2.0 * post64, 1))
+    alone = which.endswith('_alone')
+    which = which.replace('_alone', '')
     loss64 = (post64 * go_post.double()).sum() * (which != 'logvar') + (lv64 * go_lv.double()).sum() * (which != 'posterior')
     loss64.backward()
     sd = scores.to(dev).requires_grad_(True)
     oh, post, mean, lv = _HeadDppFn.apply(sd, grid_t.to(dev), grid_np.to(dev), S)
     assert not oh.requires_grad and not mean.requires_grad and post.requires_grad and lv.requires_grad
-    loss = (post * go_post.to(dev)).sum() * (which != 'logvar') + (lv * go_lv.to(dev)).sum() * (which != 'posterior')
+    if alone:
+        loss = (post * go_post.to(dev)).sum() if which == 'posterior' else (lv * go_lv.to(dev)).sum()
+    else:
+        loss = (post * go_post.to(dev)).sum() * (which != 'logvar') + (lv * go_lv.to(dev)).sum() * (which != 'posterior')
     loss.backward()
     torch.testing.assert_close(mean.cpu().double(), mean64.detach(), rtol=0, atol=1e-6)
     torch.testing.assert_close(lv.detach().cpu().double(), lv64.detach(), rtol=1e-5, atol=1e-5)

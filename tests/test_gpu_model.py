@@ -431,7 +431,7 @@ def test_f16_split_is_scale_invariant(scale, monkeypatch):
 
 
 def test_side_stream_weight_gradient_gives_the_same_bits(monkeypatch):
-    """MMLF_OVERLAP_WGRAD=1 (off by default) runs the wide blocks' first weight gradient on a side stream with its own
+    """MMLF_OVERLAP_WGRAD=1 (the default since round 6) runs the wide blocks' first weight gradient on a side stream with its own
     workspace, beside the BatchNorm-backward kernels of the block underneath: the gradients must be bit-identical to the
     single-stream order, step after step."""
     from mmlf_amd import engine

@@ -1,11 +1,14 @@
 #!/bin/bash
-# A/B of whole-step rates on ONE box by environment switch: tools/ab_env.sh OUT.log VAR VALUE_A VALUE_B ...
-out=$1; var=$2; shift; shift
+# A/B of whole-step rates on ONE box by environment switch: tools/ab_env.sh TAG VAR VALUE_A VALUE_B ...
+. "$(dirname "$0")/outdir.sh"
+out=$(new_outdir "$(basename "$1" .log)")/ab.log      # gpurun_out/TAG_<unix time>/ab.log: never an existing file
+echo "-> $out"
+var=$2; shift; shift
 for rep in 1 2; do
   for v in "$@"; do
-    env $var=$v timeout -k 10 400 python bench.py --no-cpu-baseline --no-f32-leg --steps 5 2>/dev/null | python -c "
+    env $var=$v timeout -k 10 400 python bench.py --no-cpu-baseline --no-f32-leg --steps 5 2>> "$out.err" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$var=$v', 'bs512', d['value'], 'conv_ms', d['roofline']['avg_ms'], 'wgrad_ms', d['roofline_wgrad']['avg_ms'], 'upr', d['upr']['value'], 'dpp', d['dpp']['value'], 'shard64', d['shard64']['value'], d['shard64']['vs_bs512'], 'ese', d['ese']['value'], flush=True)" >> $out || exit 1
+print('$var=$v', 'bs512', d['value'], 'conv_ms', d['roofline']['avg_ms'], 'wgrad_ms', d['roofline_wgrad']['avg_ms'], 'upr', d['upr']['value'], 'dpp', d['dpp']['value'], 'shard64', d['shard64']['value'], d['shard64']['vs_bs512'], 'ese', d['ese']['value'], flush=True)" | tee -a $out || exit 1
   done
 done

@@ -1,8 +1,10 @@
 #!/bin/bash
 # deeper counters for the dominant kernels, on the micro-benchmark (tools/kbench.py): separate --pmc passes
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_conv
-mkdir -p $OUT
+. tools/outdir.sh
+export OUT=$(new_outdir pmc_conv)      # a directory of its own per call: a retry never overwrites a failed run's logs
+python3 -c "from mmlf_amd import _lib; print(_lib.build_info())" > $OUT/build.txt 2>&1
+env | grep -E '^(AMD_|HSA_|HIP_|MMLF_|KBENCH_)' | sort > $OUT/env.txt
 export KBENCH_ONLY280=1
 pass() {  # name counters...
   name=$1; shift
@@ -14,11 +16,12 @@ pass c SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_L
 pass d TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 python3 - <<'PY'
 import csv, glob, json, collections
+import os; OUT = os.environ['OUT']
 out = collections.defaultdict(dict)
 for d in 'abcd':
     try:
-        rows = list(csv.DictReader(open(glob.glob(f'gpurun_out/pmc_conv/{d}/*/*_counter_collection.csv')[0])))
-        kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(f'gpurun_out/pmc_conv/{d}/*/*_kernel_trace.csv')[0]))}
+        rows = list(csv.DictReader(open(glob.glob(f'{OUT}/{d}/*/*_counter_collection.csv')[0])))
+        kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(f'{OUT}/{d}/*/*_kernel_trace.csv')[0]))}
     except Exception as e:
         print('pass', d, 'failed', e); continue
     s = collections.defaultdict(float); n = collections.defaultdict(set); dur = collections.defaultdict(float)
@@ -31,7 +34,7 @@ for d in 'abcd':
     for (k, c), v in s.items():
         out[k][c] = v / len(n[k])
         out[k][f'avg_ns_{d}'] = dur[k] / len(n[k])
-json.dump(out, open('gpurun_out/pmc_conv/summary.json', 'w'), indent=1)
+json.dump(out, open(OUT + '/summary.json', 'w'), indent=1)
 for k, v in out.items():
     print(k); print(json.dumps(v, indent=1))
 PY

@@ -3,10 +3,12 @@
 # request counts 2, a 128-byte one 4; TCC_EA0_WRREQ_WRITE_DRAM_32B likewise), beside what FETCH_SIZE / WRITE_SIZE are built from
 # (TCC_EA0_RDREQ, _32B, TCC_BUBBLE = 128-byte requests).  Calibration in the same passes: a torch device copy and the BatchNorm
 # row passes of tools/bn_bench.py, whose bytes are known.  Separate --pmc passes, kernel trace only.
-#   gpurun -- bash tools/pmc_exact.sh        -> gpurun_out/pmc_exact/summary.json
+#   gpurun -- bash tools/pmc_exact.sh        -> $OUT/summary.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_exact
-mkdir -p $OUT
+. tools/outdir.sh
+export OUT=$(new_outdir pmc_exact)      # a directory of its own per call: a retry never overwrites a failed run's logs
+python3 -c "from mmlf_amd import _lib; print(_lib.build_info())" > $OUT/build.txt 2>&1
+env | grep -E '^(AMD_|HSA_|HIP_|MMLF_|KBENCH_)' | sort > $OUT/env.txt
 pass() {  # prog name counters...
   prog=$1; name=$2; shift; shift
   if [ $prog = k ]; then
@@ -14,7 +16,9 @@ pass() {  # prog name counters...
   else
     timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$prog$name -- python3 tools/bn_bench.py 512 pmc > $OUT/$prog$name.log 2>&1
   fi
-  echo "pass $prog$name rc=$?"
+  rc=$?
+  echo "pass $prog$name rc=$rc"
+  return $rc              # (round 5's form ended in `echo ... rc=$?`, so the function always returned 0 and a failed pass never stopped the script)
 }
 for prog in b k; do
   pass $prog r TCC_EA0_RDREQ_DRAM_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum &&
@@ -22,12 +26,13 @@ for prog in b k; do
 done
 python3 - <<'PY'
 import csv, glob, json, collections
+import os; OUT = os.environ['OUT']
 out = collections.defaultdict(dict)
 for prog in 'bk':
   for d in 'rw':
     try:
-        rows = list(csv.DictReader(open(glob.glob(f'gpurun_out/pmc_exact/{prog}{d}/*/*_counter_collection.csv')[0])))
-        kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(f'gpurun_out/pmc_exact/{prog}{d}/*/*_kernel_trace.csv')[0]))}
+        rows = list(csv.DictReader(open(glob.glob(f'{OUT}/{prog}{d}/*/*_counter_collection.csv')[0])))
+        kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(f'{OUT}/{prog}{d}/*/*_kernel_trace.csv')[0]))}
     except Exception as e:
         print('pass', prog, d, 'failed', e); continue
     s = collections.defaultdict(float); n = collections.defaultdict(set); dur = collections.defaultdict(float)
@@ -56,7 +61,7 @@ for k, v in out.items():
         v['write_GB_exact'] = round(v['TCC_EA0_WRREQ_WRITE_DRAM_32B_sum'] * 32 / 1e9, 4)
         w, w64 = v.get('TCC_EA0_WRREQ_sum', 0), v.get('TCC_EA0_WRREQ_64B_sum', 0)
         v['write_GB_write_size_formula'] = round((w64 * 64 + (w - w64) * 32) / 1e9, 4)
-json.dump(out, open('gpurun_out/pmc_exact/summary.json', 'w'), indent=1, sort_keys=True)
+json.dump(out, open(OUT + '/summary.json', 'w'), indent=1, sort_keys=True)
 for k in sorted(out):
     v = out[k]
     print(k, {c: v[c] for c in v if c.startswith(('read_GB', 'write_GB', 'avg_ms', 'launches'))})

@@ -1,9 +1,11 @@
 #!/bin/bash
 # counters for the 70 -> 70 launches of tools/kbench.py, tiled kernel (MMLF_CONV_RS=0) against the register-streamed one
-# (MMLF_CONV_RS=1): separate --pmc passes; summary -> gpurun_out/pmc_narrow/summary.json
+# (MMLF_CONV_RS=1): separate --pmc passes; summary -> $OUT/summary.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_narrow
-mkdir -p $OUT
+. tools/outdir.sh
+export OUT=$(new_outdir pmc_narrow)      # a directory of its own per call: a retry never overwrites a failed run's logs
+python3 -c "from mmlf_amd import _lib; print(_lib.build_info())" > $OUT/build.txt 2>&1
+env | grep -E '^(AMD_|HSA_|HIP_|MMLF_|KBENCH_)' | sort > $OUT/env.txt
 export KBENCH_ONLY70=1
 pass() {  # rs name counters...
   rs=$1; name=$2; shift; shift
@@ -18,12 +20,13 @@ for rs in 0 1; do
 done
 python3 - <<'PY'
 import csv, glob, json, collections
+import os; OUT = os.environ['OUT']
 out = collections.defaultdict(dict)
 for rs in '01':
   for d in 'abdfw':
     try:
-        rows = list(csv.DictReader(open(glob.glob(f'gpurun_out/pmc_narrow/rs{rs}{d}/*/*_counter_collection.csv')[0])))
-        kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(f'gpurun_out/pmc_narrow/rs{rs}{d}/*/*_kernel_trace.csv')[0]))}
+        rows = list(csv.DictReader(open(glob.glob(f'{OUT}/rs{rs}{d}/*/*_counter_collection.csv')[0])))
+        kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(f'{OUT}/rs{rs}{d}/*/*_kernel_trace.csv')[0]))}
     except Exception as e:
         print('pass', rs, d, 'failed', e); continue
     s = collections.defaultdict(float); n = collections.defaultdict(set); dur = collections.defaultdict(float)
@@ -36,7 +39,7 @@ for rs in '01':
     for (k, c), v in s.items():
         out[k][c] = v / len(n[k])
         out[k][f'avg_ns_{d}'] = dur[k] / len(n[k])
-json.dump(out, open('gpurun_out/pmc_narrow/summary.json', 'w'), indent=1)
+json.dump(out, open(OUT + '/summary.json', 'w'), indent=1)
 for k, v in out.items():
     print(k); print(json.dumps(v, indent=1))
 PY

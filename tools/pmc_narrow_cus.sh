@@ -4,8 +4,10 @@
 # with 512 / 256 workgroups, the register-streamed kernel on 256 / 128 CUs (profiles/r05_pmc_narrow_vs_cus.log).
 #   gpurun -- bash tools/pmc_narrow_cus.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_narrow_cus
-mkdir -p $OUT
+. tools/outdir.sh
+export OUT=$(new_outdir pmc_narrow_cus)      # a directory of its own per call: a retry never overwrites a failed run's logs
+python3 -c "from mmlf_amd import _lib; print(_lib.build_info())" > $OUT/build.txt 2>&1
+env | grep -E '^(AMD_|HSA_|HIP_|MMLF_|KBENCH_)' | sort > $OUT/env.txt
 export KBENCH_ONLY70=1
 i=0
 for cfg in "MMLF_CONV_CUS=256" "MMLF_CONV_CUS=128" "MMLF_CONV_CUS=64" \
@@ -18,10 +20,11 @@ for cfg in "MMLF_CONV_CUS=256" "MMLF_CONV_CUS=128" "MMLF_CONV_CUS=64" \
 done
 python3 - <<'PY'
 import csv, glob, collections
+import os; OUT = os.environ['OUT']
 for i in range(1, 8):
   for d in 'rw':
-    rows = list(csv.DictReader(open(glob.glob(f'gpurun_out/pmc_narrow_cus/{d}{i}/*/*_counter_collection.csv')[0])))
-    kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(f'gpurun_out/pmc_narrow_cus/{d}{i}/*/*_kernel_trace.csv')[0]))}
+    rows = list(csv.DictReader(open(glob.glob(f'{OUT}/{d}{i}/*/*_counter_collection.csv')[0])))
+    kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(f'{OUT}/{d}{i}/*/*_kernel_trace.csv')[0]))}
     s = collections.defaultdict(float); n = collections.defaultdict(set); dur = collections.defaultdict(float)
     for r in rows:
         k = r['Kernel_Name'].split('(')[0]

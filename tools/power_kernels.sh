@@ -4,9 +4,10 @@
 # The environment the launches run under is part of the record (round 4's log was made with AMD_SERIALIZE_KERNEL=3 set by
 # hand, which this script did not say): the script sets it itself now -- override by exporting another value -- and writes
 # every AMD_* / HSA_* / HIP_* / MMLF_* variable in effect to $out.env, which the summary repeats in its first line.
-out=${1:-gpurun_out/power_kernels.log}
+. "$(dirname "$0")/outdir.sh"
+out=$(new_outdir "$(basename "${1:-power_kernels}" .log)")/power_kernels.log      # a directory of its own per call
+echo "-> $out"
 reps=${2:-250}
-mkdir -p "$(dirname "$out")"
 export AMD_SERIALIZE_KERNEL=${AMD_SERIALIZE_KERNEL:-3}
 env | grep -E '^(AMD_|HSA_|HIP_|MMLF_|KBENCH_)' | sort > "$out.env"
 KBENCH_STAMP=1 python tools/kbench.py 512 $reps power > "$out.kbench" 2> "$out.err" &

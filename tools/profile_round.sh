@@ -4,8 +4,10 @@
 #   gpurun -- bash tools/profile_round.sh r02
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
+. tools/outdir.sh
+export OUT=$(new_outdir prof_$TAG)      # a directory of its own per call: a retry never overwrites a failed run's logs
+python3 -c "from mmlf_amd import _lib; print(_lib.build_info())" > $OUT/build.txt 2>&1
+env | grep -E '^(AMD_|HSA_|HIP_|MMLF_|KBENCH_)' | sort > $OUT/env.txt
 CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg --no-extra-legs"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
@@ -37,7 +39,13 @@ for k in f:
         if k in m:
             out[k]['mfma_busy_frac'] = m[k][0] / (g[k][0] / 8 * 1024)
             out[k]['clock_ghz'] = g[k][0] / 8 / m[k][2]
+# which build these counters belong to: bench.py prints it as roofline.traffic_build and warns when the library it times is another one
+import os, time
+out['_meta'] = {'build': open(f'{out_dir}/build.txt').read().strip(), 'unix_time': int(time.time()),
+                'command': 'python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32-leg --no-extra-legs',
+                'env': open(f'{out_dir}/env.txt').read().split()}
 json.dump(out, open(f'{out_dir}/pmc_summary.json', 'w'), indent=1)
+out.pop('_meta')
 for k in sorted(out, key=lambda k: -out[k]['avg_ns'] * out[k]['launches'])[:8]:
     print(k, out[k])
 PY
