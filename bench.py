@@ -186,7 +186,8 @@ def extra_leg(variant, B, patch, dev, steps, peak):
     tf = value * GFLOP_PER_PATCH[variant] * (patch / 96.0) ** 2 / 1e3
     out = {'value': round(value, 2), 'unit': 'patches/s', 'steps': steps, 'per_gpu_batch': B,
            'ms_per_step': round(1e3 * dt / steps, 2), 'whole_step_tflops': round(tf, 1),
-           'frac_of_peak': round(tf / peak, 4), 'loss': round(float(loss), 6), 'host_enqueue_ms': round(host_ms, 2)}
+           'frac_of_peak': round(tf / peak, 4), 'loss': round(float(loss), 6), 'host_enqueue_ms': round(host_ms, 2),
+           'workload': workload_name(variant, 1, B, patch)}
     del step, stacks, gt, mask
     torch.cuda.empty_cache()
     return out

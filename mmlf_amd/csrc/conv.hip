@@ -1024,7 +1024,10 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
                 for (int hf = 0; hf < 2; ++hf)
                 {
                     MMLF_OOB(OOB_IN, (long long)((pk + (size_t)(16 * mb) * a.cs_in + 4 * hf + 4) - a.in) * 4 > a.in_bytes);
-                    raw[k][mb][hf] = reinterpret_cast<const float4 *>(pk + (size_t)(16 * mb) * a.cs_in)[hf];
+                    if (MMLF_ABL_RS_FUSE && a.out_shift != 0)          // proxy: a block's second convolution loads nothing
+                        raw[k][mb][hf] = make_float4(0.25f * r16, 0.5f, 0.125f * q4, 1.f);
+                    else
+                        raw[k][mb][hf] = reinterpret_cast<const float4 *>(pk + (size_t)(16 * mb) * a.cs_in)[hf];
                 }
             __builtin_amdgcn_sched_barrier(0);          // step order: the counted waits below rely on it
         }
@@ -1083,7 +1086,15 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
         }
         // (round 4 also measured this epilogue with ROW stores -- values through a wave-private LDS image, 16-byte stores of
         // consecutive addresses, 1 KB per wave instruction instead of 64-byte segments: 0.96-1.0 ms either way, removed)
-        if constexpr (TR)
+        if (MMLF_ABL_RS_FUSE && a.out_shift == 0) {                // proxy: a block's first convolution stores nothing (the
+            ConvArgs nostore = a;                                  // values are formed: they feed the row maxima)
+            nostore.n_store = 0;
+            if constexpr (TR)
+                conv_epilogue16_tr<G, EPI>(nostore, acc, Q0, wv, r16, q4, unscale_a, run_max, coef);
+            else
+                conv_epilogue16<G, EPI>(nostore, acc, Q0, wv, r16, q4, unscale_a, run_max,
+                                        a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
+        } else if constexpr (TR)
             conv_epilogue16_tr<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max, coef);
         else
             conv_epilogue16<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max,
@@ -1789,16 +1800,16 @@ extern "C" int mmlf_conv2x2_thin(const float *in, int cs_in, int K, const float 
 #else
 #define MMLF_BOUNDS_DEBUG_VALUE 0
 #endif
-extern "C" int mmlf_build_is_ablation(void) { return (MMLF_ABL_TERMS != 3 || MMLF_ABL_WGRAD_STAGE != 0) ? 1 : 0; }
+extern "C" int mmlf_build_is_ablation(void) { return (MMLF_ABL_TERMS != 3 || MMLF_ABL_WGRAD_STAGE != 0 || MMLF_ABL_RS_FUSE != 0) ? 1 : 0; }
 extern "C" const char *mmlf_build_info(void)
 {
     static char text[448];
     static std::once_flag once;
     std::call_once(once, [] {
         snprintf(text, sizeof(text),
-                 "abi=%d git=%s src=%s MMLF_ABL_TERMS=%d MMLF_ABL_WGRAD_STAGE=%d MMLF_GRID_PAD_W=%d MMLF_GRID_PAD_H=%d MMLF_RING16=%d "
+                 "abi=%d git=%s src=%s MMLF_ABL_TERMS=%d MMLF_ABL_WGRAD_STAGE=%d MMLF_ABL_RS_FUSE=%d MMLF_GRID_PAD_W=%d MMLF_GRID_PAD_H=%d MMLF_RING16=%d "
                  "MMLF_WGRAD_EARLY=%d MMLF_WGRADN_CLAMP=%d MMLF_WGRAD_ZEROPAD=%d MMLF_BOUNDS_DEBUG=%d ablation=%d",
-                 MMLF_ABI_VERSION, MMLF_GIT_HASH, MMLF_SRC_HASH, MMLF_ABL_TERMS, MMLF_ABL_WGRAD_STAGE, MMLF_GRID_PAD_W, MMLF_GRID_PAD_H,
+                 MMLF_ABI_VERSION, MMLF_GIT_HASH, MMLF_SRC_HASH, MMLF_ABL_TERMS, MMLF_ABL_WGRAD_STAGE, MMLF_ABL_RS_FUSE, MMLF_GRID_PAD_W, MMLF_GRID_PAD_H,
                  MMLF_RING16, MMLF_WGRAD_EARLY, MMLF_WGRADN_CLAMP, MMLF_WGRAD_ZEROPAD, MMLF_BOUNDS_DEBUG_VALUE, mmlf_build_is_ablation());
     });
     return text;

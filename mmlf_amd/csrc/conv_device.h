@@ -32,7 +32,8 @@ __device__ __forceinline__ int mmlf_records_left(long long total, long long off)
 // them).  What is left changes either nothing observable (MMLF_RING16, MMLF_WGRAD_EARLY, MMLF_WGRADN_CLAMP, MMLF_WGRAD_ZEROPAD:
 // tuning constants and equivalent forms) or the RESULT:
 //   MMLF_ABL_TERMS < 3 -- run only 2 or 1 of the f16 split's three cross terms (a timing ablation: WRONG results);
-//   MMLF_ABL_WGRAD_STAGE -- timing ablations of the wide weight gradient's staging (below: WRONG results).
+//   MMLF_ABL_WGRAD_STAGE -- timing ablations of the wide weight gradient's staging (below: WRONG results);
+//   MMLF_ABL_RS_FUSE -- timing proxy of a fused evaluation stream block (below: WRONG results).
 // mmlf_build_info() reports every one of them and the Python loader refuses a library with a result-changing switch
 // unless MMLF_ALLOW_ABLATION=1 is set (mmlf_amd/_lib.py).
 #ifndef MMLF_ABL_TERMS
@@ -44,6 +45,11 @@ __device__ __forceinline__ int mmlf_records_left(long long total, long long off)
                                  // could save at most); 2 = it is neither loaded nor stored after the first chunk (what staging
                                  // it ONCE per chunk for all six slices could save at most); 3 = nothing is staged after the first
                                  // chunk (matrix instructions, fragment reads and the barrier alone)
+#ifndef MMLF_ABL_RS_FUSE
+#define MMLF_ABL_RS_FUSE 0       // round-6 timing proxy of a FUSED evaluation stream block (WRONG results): in the register-streamed
+#endif                           // narrow kernel, pad-1 launches (a block's first convolution) store nothing and pad-0 launches (its
+                                 // second) load no activations -- what conv(p1)+ReLU+conv(p0) of a block could cost at the very least
+                                 // if the intermediate never left the CU (the exchange through LDS is NOT counted): EXPERIMENTS.md 4.10
 #ifndef MMLF_RING16
 #define MMLF_RING16 3   // pipeline depth of the sixteen-wave conv variant (LDS: 30 KB per buffer + 20 KB; 4 measures the same)
 #endif

@@ -54,7 +54,8 @@ def _worker(rank, world, port, out_dir, variant='upr'):
         losses = [float(step(*[s[lo:hi].contiguous() for s in stacks], gt[lo:hi].contiguous(),
                              mask[lo:hi].contiguous(), it)) for it in (1, 2)]
         torch.cuda.synchronize()
-        torch.save({'flat': step.flat.cpu(), 'losses': losses, 'fired': fired}, os.path.join(out_dir, f'r{rank}.pt'))
+        torch.save({'flat': step.flat.cpu(), 'losses': losses, 'fired': fired, 'grad': step.grad.cpu() / world},
+                   os.path.join(out_dir, f'r{rank}.pt'))
     finally:
         dist.destroy_process_group()
 
@@ -97,6 +98,14 @@ def test_two_ranks_one_gpu_native_path(tmp_path, variant):
     torch.testing.assert_close(r0['flat'][solid.cpu()], steps[0].flat.cpu()[solid.cpu()], rtol=1e-4, atol=atol)
     # ... and an INDEPENDENT reference: the same two shards through the stock-torch module path on the CPU
     # (nn.Conv2d / BatchNorm2d / autograd), gradients averaged by hand, the same Adam arithmetic
+    # Conditioning of that comparison: Adam's update is lr * m / sqrt(v), so a gradient difference d on an element of magnitude
+    # |g| moves its weight by ~ lr * d / |g|.  UPR: this library's gradients differ from the CPU's by ~1e-8 absolute and every
+    # element above 1e-5 is held to 3e-5.  DPP: the cross entropy's gradients are sums of softmax - target terms that cancel
+    # (they add up to zero over the classes of a pixel), so the float32 noise of the two implementations is ~1e-6 absolute next
+    # to many gradients of 1e-5: there the comparison is made where it is conditioned -- elements above 1e-3 in both steps, 10 %
+    # of an lr step -- and the per-step ALL-REDUCED GRADIENT of the ranks is held against the CPU reference directly.
+    cpu_floor, cpu_atol = (1e-3, 1e-3) if variant == 'dpp' else (1e-5, atol)
+    cpu_solid = None
     cpu_steps = [TrainStep(_mk(3).cpu(), lr=1e-2, loss_margin=3) for _ in range(2)]
     cstacks, cgt, cmargin = [s.cpu() for s in stacks], gt.cpu(), margin.cpu()
     for it in (1, 2):
@@ -109,11 +118,18 @@ def test_two_ranks_one_gpu_native_path(tmp_path, variant):
             if r == 0:
                 np.testing.assert_allclose(float(loss), r0['losses'][it - 1], rtol=2e-5)
         avg = (cpu_steps[0].grad + cpu_steps[1].grad) / 2
+        ok = avg.abs() > cpu_floor
+        cpu_solid = ok if cpu_solid is None else cpu_solid & ok
         for st in cpu_steps:
             st.grad.copy_(avg)
             st.adam_steps += 1
             st._adam(st.current_lr(it), 1.0)
-    torch.testing.assert_close(r0['flat'][solid.cpu()], cpu_steps[0].flat[solid.cpu()], rtol=1e-4, atol=atol)
+    # the ranks' last all-reduced gradient (step 2, on weights that went through one update) against the CPU reference's
+    rel = float((r0['grad'] - avg).norm() / avg.norm())
+    assert rel <= 2e-2, rel
+    cpu_solid &= solid.cpu()
+    assert float(cpu_solid.float().mean()) > (0.02 if variant == 'dpp' else 0.5)
+    torch.testing.assert_close(r0['flat'][cpu_solid], cpu_steps[0].flat[cpu_solid], rtol=1e-4, atol=cpu_atol)
 
 
 def test_bench_two_ranks_gloo_rehearsal(tmp_path):
@@ -136,6 +152,15 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     assert line['n_gpus'] == 2 and line['config']['per_gpu_batch'] == 4 and line['config']['parallelism'] == 'dp2'
     assert line['scaling'] == 'strong' and line['value'] > 0 and np.isfinite(line['config']['loss'])
     assert 'gloo' in line['config']['backend']
+    # round 6: the workload names itself (not a BASELINE shape here), the line carries the host's enqueue time and one wait per
+    # bucket, and the DPP / UPR variants run through the same two-rank path (BASELINE.json configs[3] is DPP under data parallelism)
+    assert 'not a BASELINE.json shape' in line['config']['workload'] and '2 GPUs, data parallel' in line['config']['workload']
+    assert line['host_enqueue_ms'] > 0 and len(line['allreduce_ms_by_bucket']) == line['config']['buckets']
+    for v in ('dpp', 'upr'):
+        leg = line[v]
+        assert leg['value'] > 0 and np.isfinite(leg['loss']) and leg['per_gpu_batch'] == 4 and leg['buckets'] == line['config']['buckets']
+        assert len(leg['allreduce_ms_by_bucket']) == leg['buckets'] and v.upper() in leg['workload']
+    assert line['dpp']['gradient_bytes'] > line['config']['gradient_bytes']          # the 108-channel head
     # BASELINE.json configs[4] under --gpus N: one light field per rank, replicas only, slowest rank reported
     rep = line['ese_replicas']
     assert rep['scenes'] == 2 and rep['members'] == 70 and rep['finite'] and rep['value'] > 0
