@@ -469,7 +469,9 @@ __device__ __forceinline__ void conv_epilogue16_tr(const ConvArgs &a, const f32x
                 asm("v_max_f32 %0, %1, |%2|" : "=v"(mk[mb]) : "v"(mk[mb]), "v"(v));
                 st[r] = __float_as_uint(v);
             }
-            if (c0 < a.n_store) {
+            // (MMLF_ABL_RS_FUSE, timing proxy: the 80-column kernels' pad-1 launches -- a stream block's first convolution -- store
+            //  nothing; the values are still formed, they feed the row maxima)
+            if (c0 < a.n_store && !(MMLF_ABL_RS_FUSE && G == 5 && a.out_shift == 0)) {
                 MMLF_OOB(OOB_OUT, (long long)lo + 64 * nb + (long long)(16 * mb) * a.cs_out * 4 + 12 >= ob_left);
                 __builtin_amdgcn_raw_buffer_store_b128(st, ob, lo + 64 * nb, (unsigned)(16 * mb) * a.cs_out * 4u, 0);
             }
@@ -1086,15 +1088,7 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
         }
         // (round 4 also measured this epilogue with ROW stores -- values through a wave-private LDS image, 16-byte stores of
         // consecutive addresses, 1 KB per wave instruction instead of 64-byte segments: 0.96-1.0 ms either way, removed)
-        if (MMLF_ABL_RS_FUSE && a.out_shift == 0) {                // proxy: a block's first convolution stores nothing (the
-            ConvArgs nostore = a;                                  // values are formed: they feed the row maxima)
-            nostore.n_store = 0;
-            if constexpr (TR)
-                conv_epilogue16_tr<G, EPI>(nostore, acc, Q0, wv, r16, q4, unscale_a, run_max, coef);
-            else
-                conv_epilogue16<G, EPI>(nostore, acc, Q0, wv, r16, q4, unscale_a, run_max,
-                                        a.bn_partial ? stats_all + (size_t)w * NP * 2 : nullptr);
-        } else if constexpr (TR)
+        if constexpr (TR)
             conv_epilogue16_tr<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max, coef);
         else
             conv_epilogue16<G, EPI>(a, acc, Q0, wv, r16, q4, unscale_a, run_max,

@@ -51,10 +51,13 @@ def _worker(rank, world, port, out_dir, variant='upr'):
         step.buckets.ready = lambda g, key: (fired.append(key), orig(g, key))[1]
         stacks, gt, mask = _data()
         lo, hi = rank * B // world, (rank + 1) * B // world
-        losses = [float(step(*[s[lo:hi].contiguous() for s in stacks], gt[lo:hi].contiguous(),
-                             mask[lo:hi].contiguous(), it)) for it in (1, 2)]
+        losses, grads = [], []
+        for it in (1, 2):
+            losses.append(float(step(*[s[lo:hi].contiguous() for s in stacks], gt[lo:hi].contiguous(),
+                                     mask[lo:hi].contiguous(), it)))
+            grads.append(step.grad.cpu() / world)            # the all-reduced gradient of this step, averaged
         torch.cuda.synchronize()
-        torch.save({'flat': step.flat.cpu(), 'losses': losses, 'fired': fired, 'grad': step.grad.cpu() / world},
+        torch.save({'flat': step.flat.cpu(), 'losses': losses, 'fired': fired, 'grads': grads},
                    os.path.join(out_dir, f'r{rank}.pt'))
     finally:
         dist.destroy_process_group()
@@ -105,7 +108,7 @@ def test_two_ranks_one_gpu_native_path(tmp_path, variant):
     # to many gradients of 1e-5: there the comparison is made where it is conditioned -- elements above 1e-3 in both steps, 10 %
     # of an lr step -- and the per-step ALL-REDUCED GRADIENT of the ranks is held against the CPU reference directly.
     cpu_floor, cpu_atol = (1e-3, 1e-3) if variant == 'dpp' else (1e-5, atol)
-    cpu_solid = None
+    cpu_solid, rel = None, []
     cpu_steps = [TrainStep(_mk(3).cpu(), lr=1e-2, loss_margin=3) for _ in range(2)]
     cstacks, cgt, cmargin = [s.cpu() for s in stacks], gt.cpu(), margin.cpu()
     for it in (1, 2):
@@ -120,13 +123,14 @@ def test_two_ranks_one_gpu_native_path(tmp_path, variant):
         avg = (cpu_steps[0].grad + cpu_steps[1].grad) / 2
         ok = avg.abs() > cpu_floor
         cpu_solid = ok if cpu_solid is None else cpu_solid & ok
+        rel.append(float((r0['grads'][it - 1] - avg).norm() / avg.norm()))
         for st in cpu_steps:
             st.grad.copy_(avg)
             st.adam_steps += 1
             st._adam(st.current_lr(it), 1.0)
-    # the ranks' last all-reduced gradient (step 2, on weights that went through one update) against the CPU reference's
-    rel = float((r0['grad'] - avg).norm() / avg.norm())
-    assert rel <= 2e-2, rel
+    # the ranks' all-reduced gradients against the CPU reference's: step 1 on identical weights (float32 level), step 2 on weights
+    # that went through one Adam update (elements whose step-1 gradient is rounding noise moved by +-lr in either implementation)
+    assert rel[0] <= 1e-3 and rel[1] <= 1e-1, rel
     cpu_solid &= solid.cpu()
     assert float(cpu_solid.float().mean()) > (0.02 if variant == 'dpp' else 0.5)
     torch.testing.assert_close(r0['flat'][cpu_solid], cpu_steps[0].flat[cpu_solid], rtol=1e-4, atol=cpu_atol)
