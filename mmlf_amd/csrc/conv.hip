@@ -1009,12 +1009,19 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
     const size_t row_off = (size_t)r16 * a.cs_in;                                     // floats
     const size_t rem_off = (size_t)((q4 & 1) + (q4 >> 1) * a.P) * a.cs_in + 32 * NS;
 
+    const int gi0 = gi;                                                               // (used by the MMLF_ABL_RS_FUSE proxy only)
     for (; gi < gend; gi += gstep) {
         const long long Q0 = (long long)(gi >> 3) * MMLF_TILE;
         const int wv = gi & 7;
+        // (MMLF_ABL_RS_FUSE, timing proxy: a pad-0 launch -- a stream block's second convolution -- reads the activations AND row
+        //  maxima of the wave's FIRST group every time: real values with real sparsity (the matrix cores' power follows the data),
+        //  served by the caches instead of memory, as a fused block's intermediate would be served by LDS)
+        const bool abl_reuse = MMLF_ABL_RS_FUSE && a.out_shift != 0;
+        const long long Qa = abl_reuse ? (long long)(gi0 >> 3) * MMLF_TILE : Q0;
+        const int wa = abl_reuse ? (gi0 & 7) : wv;
         // row maxima first (their loads are the oldest: the first counted wait below covers them)
-        const float gathered = wave_operand_amax_gather(a, Q0, wv, lane);
-        const float *p0 = a.in + (size_t)(Q0 + 32 * wv) * a.cs_in + row_off;
+        const float gathered = wave_operand_amax_gather(a, Qa, wa, lane);
+        const float *p0 = a.in + (size_t)(Qa + 32 * wa) * a.cs_in + row_off;
         float4 raw[NSTEP][2][2];                                   // [step][row block][half]
 #pragma unroll
         for (int k = 0; k < NSTEP; ++k) {
@@ -1026,10 +1033,7 @@ __global__ __launch_bounds__(512, 2) void conv4tap_rs_kernel(ConvArgs a, int ngr
                 for (int hf = 0; hf < 2; ++hf)
                 {
                     MMLF_OOB(OOB_IN, (long long)((pk + (size_t)(16 * mb) * a.cs_in + 4 * hf + 4) - a.in) * 4 > a.in_bytes);
-                    if (MMLF_ABL_RS_FUSE && a.out_shift != 0)          // proxy: a block's second convolution loads nothing
-                        raw[k][mb][hf] = make_float4(0.25f * r16, 0.5f, 0.125f * q4, 1.f);
-                    else
-                        raw[k][mb][hf] = reinterpret_cast<const float4 *>(pk + (size_t)(16 * mb) * a.cs_in)[hf];
+                    raw[k][mb][hf] = reinterpret_cast<const float4 *>(pk + (size_t)(16 * mb) * a.cs_in)[hf];
                 }
             __builtin_amdgcn_sched_barrier(0);          // step order: the counted waits below rely on it
         }
