@@ -512,8 +512,10 @@ def main():
             line['allreduce_ms_by_bucket'] = allreduce_by_bucket
             line['allreduce_note'] = ('per step, max over ranks: time the compute stream waits for the bucket all-reduces '
                                       'after backward is enqueued (0 = fully overlapped with backward); by_bucket in firing order')
-            line['host_enqueue_note'] = ('host_enqueue_ms: wall time until step() returns, nothing waited for, max over ranks; '
-                                         'a rank is launch-bound when this approaches ms_per_step')
+            line['host_enqueue_note'] = ('host_enqueue_ms: wall time until step() returns, max over ranks; a rank is launch-bound when '
+                                         'this approaches ms_per_step'
+                                         + (' -- NOT under gloo: its waits block the host until the gradient exists, so the figure equals '
+                                            'the step time here; under RCCL a wait is a stream dependency' if args.backend != 'nccl' else ''))
             for v, leg in ddp_legs.items():
                 line[v] = leg
         if args.backend != 'nccl':
