@@ -33,7 +33,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 / f16 MFMA; the split kernels spend 3 (f16x3) or 6 (bf16x6) passes per f32 product
 # the committed rocprofv3 PMC passes `roofline.traffic` is read from (tools/profile_round.sh writes it; ONE file, named in
 # the line as `traffic_source`: an older round's numbers are never substituted silently)
-PMC_SUMMARY = os.environ.get('MMLF_PMC_SUMMARY', os.path.join('profiles', 'r05_pmc_bs512_base_summary.json'))
+PMC_SUMMARY = os.environ.get('MMLF_PMC_SUMMARY', os.path.join('profiles', 'r06_pmc_bs512_base_summary.json'))
 KW_EXTRA = {'base': {}, 'upr': {'model_uncert': True}, 'dpp': {'model_discrete': True}}
 
 
