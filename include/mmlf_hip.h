@@ -41,7 +41,7 @@ const char *mmlf_last_error(void);
 /* Bumped whenever an entry point's arguments or a layout they share changes.  mmlf_abi_version() returns the value the
  * library was BUILT with: a binding compares it with the header it was written against (mmlf_amd/_lib.py does, and reads
  * the number from this line) before making any other call. */
-#define MMLF_ABI_VERSION 7
+#define MMLF_ABI_VERSION 8
 int mmlf_abi_version(void);
 
 /* What the binary is: one line with the ABI version, the source revision it was built from and the value of every build
@@ -310,6 +310,13 @@ int mmlf_adam_step(float *p, const float *g, float *m, float *v, int64_t n, doub
 int mmlf_shift_views(const float *h, const float *v, const float *i, const float *d,
                      float *oh, float *ov, float *oi, float *od, const int32_t *tab_s, const float *tab_w,
                      int S, int views, int H, int W, void *stream);
+/* The same shear of ONE view stack for S shift values, written straight into the padded NHWC grid the trunk reads (the member
+ * batch of mmlf/model/ensamble.py:61-76 without the (S,views,3,H,W) intermediate: mmlf_shift_views + mmlf_pack_nchw in one
+ * pass, the same bits).  kind: 0 = horizontal stack (along W), 1 = vertical (along H), 2 = increasing diagonal (W, then H with
+ * the negated shift, hci4d.py:971-975), 3 = decreasing diagonal (W, then H).  in: (views,3,H,W); grid: S images of the grid
+ * layout, channel stride cs >= 3 views (pad channels and borders written as zeros); amax_out: the grid's amax array or NULL. */
+int mmlf_shift_pack(const float *in, int kind, float *grid, int cs, const int32_t *tab_s, const float *tab_w,
+                    int S, int views, int H, int W, float *amax_out, void *stream);
 /* Ensamble reduction (mmlf/model/ensamble.py:78-101): means/logvars (S,B,H,W) ->
  * mean, logvar (arg-min logvar member), posterior (B,S,H,W) = mean of S Laplacians on grid[S]. */
 int mmlf_ensamble_reduce(const float *means, const float *logvars, const float *grid, float *mean,

@@ -72,6 +72,7 @@ SIGNATURES = {
     'mmlf_loss_multi_fwd_bwd': (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _d, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     'mmlf_adam_step': (_i, [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i64, _d, _vp]),
     'mmlf_shift_views': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'mmlf_shift_pack': (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     'mmlf_lmm_to_discrete': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp]),
     'mmlf_patch_gather': (_i, [_vp] * 5 + [_i] * 5 + [_vp] * 12 + [_i, _i, _vp]),
     'mmlf_patch_contrast': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -118,6 +119,11 @@ def load():
     """Load the shared library once; raise if it is absent (no fallback)."""
     global _lib, BUILD_INFO
     if _lib is None:
+        # torch FIRST: it ships a HIP runtime of its own (torch/lib/libamdhip64.so) and this library is linked against the
+        # system's (/opt/rocm/lib).  Loaded in the other order the process holds two runtimes and the first launch fails with
+        # "no ROCm-capable device is detected" (seen when `python __graft_entry__.py smoke` loaded the library in build(), before
+        # anything had imported torch); with torch's runtime already mapped the loader resolves this library's dependency to it.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f'{LIB_PATH} not found: build it with `python -m mmlf_amd.csrc.build` '

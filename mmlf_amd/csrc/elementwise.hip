@@ -973,6 +973,76 @@ __global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ h,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Shift + pack (round 6): the Ensamble's members (ensamble.py:61-76) go from the four view stacks straight into the padded NHWC
+// grid the trunk reads -- mmlf_shift_views followed by mmlf_pack_nchw in one pass per stream, without the (S, views, 3, H, W)
+// intermediate (7.9 GB written and read again per 512 x 512 scene).  The arithmetic per sample is shift_kernel's, operation for
+// operation (the two launches write the same bits: tests/test_ensamble.py); the transpose through LDS is pack_nchw_kernel's.
+// KIND: 0 = horizontal stack (roll along W), 1 = vertical (along H), 2 = increasing diagonal (W, then H with the NEGATED
+// shift, hci4d.py:971-975), 3 = decreasing diagonal (W, then H).
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void shift_pack_kernel(const float *__restrict__ src, int views, float *__restrict__ grid,
+                                                         int cs, const int32_t *__restrict__ tab_s,
+                                                         const float *__restrict__ tab_w, int H, int W,
+                                                         float *__restrict__ amax, int xt)
+{
+    extern __shared__ float tile[];            // [cs][xt | 1] channel-major, then the member's shift table
+    const int P = W + MMLF_GRID_PAD_W, R = H + MMLF_GRID_PAD_H;
+    const int C = views * 3;
+    const int row = blockIdx.x;                // (member s, grid row y)
+    const int s = row / R, y = row - s * R;
+    const size_t base = (size_t)row * P;
+    const int c4n = cs / 4;
+    const int pitch = xt | 1;
+    ShiftTab *tab = reinterpret_cast<ShiftTab *>(tile + (size_t)cs * pitch);      // [views]
+    for (int k = threadIdx.x; k < views; k += blockDim.x) {
+        tab[k].s0 = tab_s[2 * (s * views + k)]; tab[k].s1 = tab_s[2 * (s * views + k) + 1];
+        tab[k].w0 = tab_w[2 * (s * views + k)]; tab[k].w1 = tab_w[2 * (s * views + k) + 1];
+    }
+    __syncthreads();
+    const bool row_in = (y >= 1 && y <= H);
+    const int yi = y - 1;
+    float mx = 0.f;
+    for (int x0 = 0; x0 < P; x0 += xt) {
+        const int nx = min(xt, P - x0);
+        for (int e = threadIdx.x; e < cs * nx; e += blockDim.x) {
+            const int c = e / nx, x = x0 + e - c * nx;         // x fastest: coalesced plane reads
+            float v = 0.f;
+            if (row_in && x >= 1 && x <= W && c < C) {
+                const int view = c / 3;
+                const ShiftTab t = tab[view];
+                const float *p = src + (size_t)c * H * W;       // plane (view, colour) = channel c
+                const int xi = x - 1;
+                auto lerp = [&](float a, float b) { return __fadd_rn(__fmul_rn(a, t.w0), __fmul_rn(b, t.w1)); };
+                if (KIND == 0) {
+                    v = lerp(p[(size_t)yi * W + roll_src(xi, t.s0, W)], p[(size_t)yi * W + roll_src(xi, t.s1, W)]);
+                } else if (KIND == 1) {
+                    v = lerp(p[(size_t)roll_src(yi, t.s0, H) * W + xi], p[(size_t)roll_src(yi, t.s1, H) * W + xi]);
+                } else {
+                    const int sg = KIND == 2 ? -1 : 1;
+                    const int xa = roll_src(xi, t.s0, W), xb = roll_src(xi, t.s1, W);
+                    const int ya = roll_src(yi, sg * t.s0, H), yb = roll_src(yi, sg * t.s1, H);
+                    const float ta = lerp(p[(size_t)ya * W + xa], p[(size_t)ya * W + xb]);
+                    const float tb = lerp(p[(size_t)yb * W + xa], p[(size_t)yb * W + xb]);
+                    v = lerp(ta, tb);
+                }
+            }
+            tile[c * pitch + (x - x0)] = v;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nx * c4n; e += blockDim.x) {
+            const int xl = e / c4n, cg = e - xl * c4n;         // channel group fastest: coalesced grid writes
+            const float4 o = make_float4(tile[(4 * cg) * pitch + xl], tile[(4 * cg + 1) * pitch + xl],
+                                         tile[(4 * cg + 2) * pitch + xl], tile[(4 * cg + 3) * pitch + xl]);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+            *reinterpret_cast<float4 *>(grid + (base + x0 + xl) * cs + 4 * cg) = o;
+        }
+        __syncthreads();
+    }
+    if (amax) mmlf_amax_update_row(mx, amax, row);      // this workgroup wrote grid row `row`
+}
+
+// ---------------------------------------------------------------------------------------------
 // Training patch pipeline: the transform chain of reference train/cli.py:72-91 on scenes cached in HBM,
 // fused into one gather per output pixel.  Per sample (host-drawn parameters, reference call order):
 // DownSampling f (hci4d.py:483-510) -> Shift disp (:907-990) -> Crop at (y0,x0) (:532-575; RandomCrop +
@@ -1525,6 +1595,28 @@ extern "C" int mmlf_shift_views(const float *h, const float *v, const float *i, 
     hipLaunchKernelGGL(shift_kernel, dim3(S * views * 3 * H), dim3(256), 0, (hipStream_t)stream, h, v, i, d, oh, ov,
                        oi, od, tab_s, tab_w, views, H, W);
     return mmlf_launch_status("mmlf_shift_views");
+}
+
+extern "C" int mmlf_shift_pack(const float *in, int kind, float *grid, int cs, const int32_t *tab_s, const float *tab_w,
+                               int S, int views, int H, int W, float *amax_out, void *stream)
+{
+    MMLF_CHECK_ARG(in && grid && tab_s && tab_w, "mmlf_shift_pack: null pointer");
+    MMLF_CHECK_ARG(kind >= 0 && kind <= 3, "mmlf_shift_pack: kind=%d", kind);
+    MMLF_CHECK_ARG(S > 0 && views > 0 && H > 0 && W > 0 && cs % 4 == 0 && views * 3 <= cs, "mmlf_shift_pack: S=%d views=%d cs=%d",
+                   S, views, cs);
+    int xt = PACK_XT;
+    while (xt > 4 && (size_t)cs * (xt | 1) * sizeof(float) > 32 * 1024) xt >>= 1;
+    const size_t lds = (size_t)cs * (xt | 1) * sizeof(float) + (size_t)views * sizeof(ShiftTab);
+    MMLF_CHECK_ARG(lds <= 64 * 1024, "mmlf_shift_pack: cs=%d does not fit the transpose tile", cs);
+    const dim3 g((unsigned)(S * (H + MMLF_GRID_PAD_H))), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+    case 0: hipLaunchKernelGGL(shift_pack_kernel<0>, g, b, lds, st, in, views, grid, cs, tab_s, tab_w, H, W, amax_out, xt); break;
+    case 1: hipLaunchKernelGGL(shift_pack_kernel<1>, g, b, lds, st, in, views, grid, cs, tab_s, tab_w, H, W, amax_out, xt); break;
+    case 2: hipLaunchKernelGGL(shift_pack_kernel<2>, g, b, lds, st, in, views, grid, cs, tab_s, tab_w, H, W, amax_out, xt); break;
+    default: hipLaunchKernelGGL(shift_pack_kernel<3>, g, b, lds, st, in, views, grid, cs, tab_s, tab_w, H, W, amax_out, xt); break;
+    }
+    return mmlf_launch_status("mmlf_shift_pack");
 }
 
 extern "C" int mmlf_ensamble_reduce(const float *means, const float *logvars, const float *grid, float *mean,

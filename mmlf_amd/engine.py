@@ -526,27 +526,39 @@ class Trunk:
             rec_list.append(rec)
         return out, cs_out
 
-    def forward(self, p, stacks, train, save):
+    def forward(self, p, stacks, train, save, packed=None):
         """stacks: four (B, views, 3, H, W) contiguous float32 device tensors.
+        packed (instead of stacks): (Geometry, [four grid tensors of channel stride cs_of(3 views), with their amax arrays]) --
+        inputs some other kernel already wrote in the grid layout (the Ensamble's mmlf_shift_pack).
         Returns (output NCHW (B,oc,H,W), ctx or None)."""
-        h = stacks[0]
-        B, n, c, H, W = h.shape
-        dev = h.device
-        geo = Geometry(B, H, W)
-        cin0 = n * c
+        if packed is not None:
+            geo, xs_in = packed
+            B, H, W = geo.B, geo.H, geo.W
+            dev = xs_in[0].device
+            cin0 = self.views * 3
+        else:
+            h = stacks[0]
+            B, n, c, H, W = h.shape
+            dev = h.device
+            geo = Geometry(B, H, W)
+            cin0 = n * c
         _Workspace.get(dev).enter_stream()
         packs = self._prepack(p, dev, save)
         tracked = []                  # BatchNorm counters of this pass: ONE increment launch at its end
         tape = {'geo': geo, 'streams': [], 'out': [], 'packs': packs}
-        concat, *xs = geo.bufs([4 * self.chs] + [cs_of(cin0)] * 3, dev)
-        xs.append(geo.buf(cs_of(cin0), dev))
+        if packed is not None:
+            concat, xs = geo.buf(4 * self.chs, dev), list(xs_in)
+        else:
+            concat, *xs = geo.bufs([4 * self.chs] + [cs_of(cin0)] * 3, dev)
+            xs.append(geo.buf(cs_of(cin0), dev))
         # the four streams' last BatchNorm-apply passes write quarter rows of the concat buffer: one pass for all four
         # (whole rows) when they are real passes (not folded into conv2) and the channel count allows it
         fold = not train and not save
         deferred = [] if (APPLY4 and not fold and self.chs % 2 == 0 and all(b[-1].bn for _, _, b in self.streams)) else None
         for s, (key, var, blocks) in enumerate(self.streams):
             x = xs[s]
-            call('mmlf_pack_nchw', ptr(stacks[s]), cin0, ptr(x), cs_of(cin0), B, H, W, ptr(x.absmax), _lib.stream_ptr())
+            if packed is None:
+                call('mmlf_pack_nchw', ptr(stacks[s]), cin0, ptr(x), cs_of(cin0), B, H, W, ptr(x.absmax), _lib.stream_ptr())
             cs_x = cs_of(cin0)
             recs = []
             for k, spec in enumerate(blocks):

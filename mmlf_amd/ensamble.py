@@ -11,6 +11,7 @@ affine map, so batching members is exact), and one kernel does the fusion (``mml
 On CPU tensors the same arithmetic runs in torch ops, member by member.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -19,6 +20,10 @@ import torch.nn as nn
 from . import _lib
 from ._lib import call, ptr
 from .feed_forward import laplacian
+
+
+# MMLF_ESE_FUSED=0: the members go through mmlf_shift_views and the module's own forward (A/B of the fused member path)
+FUSED_MEMBERS = os.environ.get('MMLF_ESE_FUSED', '1') != '0'
 
 
 def shift_table(disps, views):
@@ -127,10 +132,31 @@ class Ensamble(nn.Module):
         offs = torch.from_numpy(disps.astype(np.float32)).to(dev)
         means = torch.empty((S, b, hh, ww), dtype=torch.float32, device=dev)
         logvars = torch.empty_like(means)
+        # Fused member path (round 6): the shear writes the trunk's own input layout (mmlf_shift_pack: no (n, views, 3, H, W)
+        # intermediate, no pack pass) and the members' UPR `posterior` -- 108 planes per member that ensamble.py:66-76 never
+        # reads -- is not formed.  Same bits as the path below (tests/test_ensamble.py).  For the uncertainty model itself, in
+        # evaluation, outside autograd; anything else (a DataParallel wrapper, another head) takes the module's own forward.
+        fused = (FUSED_MEMBERS and model is inner and getattr(inner, '_native_ok', False) and getattr(inner, 'uncert', False)
+                 and not inner.training and not torch.is_grad_enabled() and views == inner.views and c == 3)
         for bi in range(b):
             src = [t[bi].contiguous() for t in (h, v, i, d)]
             for s0 in range(0, S, chunk):
                 n = min(chunk, S - s0)
+                if fused:
+                    from . import engine
+                    _lib.load()
+                    with torch.cuda.device(dev):
+                        geo = engine.Geometry(n, hh, ww)
+                        cs = engine.cs_of(views * c)
+                        xs = geo.bufs([cs] * 4, dev)
+                        for kind, (t, x) in enumerate(zip(src, xs)):
+                            call('mmlf_shift_pack', ptr(t), kind, ptr(x), cs, ptr(tab_s[s0:s0 + n]), ptr(tab_w[s0:s0 + n]),
+                                 n, views, hh, ww, ptr(x.absmax), _lib.stream_ptr())
+                        out, _ = inner._trunk.forward(inner._tensor_dict(), None, False, False, packed=(geo, xs))
+                        del xs
+                    means[s0:s0 + n, bi] = out[:, 0] + offs[s0:s0 + n].view(-1, 1, 1)
+                    logvars[s0:s0 + n, bi] = out[:, 1]
+                    continue
                 outs = [torch.empty((n, views, c, hh, ww), dtype=torch.float32, device=dev) for _ in range(4)]
                 call('mmlf_shift_views', *[ptr(t) for t in src], *[ptr(t) for t in outs],
                      ptr(tab_s[s0:s0 + n]), ptr(tab_w[s0:s0 + n]), n, views, hh, ww, _lib.stream_ptr())

@@ -85,14 +85,56 @@ def test_shift_hip_matches_reference():
 
 
 @pytest.mark.gpu
-def test_ensamble_hip_matches_reference():
+@pytest.mark.parametrize('shape', [(24, 24), (9, 40), (33, 17)])
+def test_shift_pack_writes_the_same_bits_as_shift_then_pack(shape):
+    """mmlf_shift_pack (round 6: the Ensamble's members sheared straight into the trunk's grid layout) against
+    mmlf_shift_views followed by mmlf_pack_nchw, per stream kind: the same grid bytes (borders, pad channels and slack
+    included) and the same amax array; the shifts are the golden's (hci4d.py:907-990 is pinned by test_shift_hip_matches_reference)."""
+    from mmlf_amd import _lib, engine
+    from mmlf_amd._lib import call, ptr
+    dev = torch.device('cuda:0')
+    H, W = shape
+    views = 9
+    gen = torch.Generator().manual_seed(H * 100 + W)
+    src = [torch.rand((views, 3, H, W), generator=gen).to(dev) for _ in range(4)]
+    disps = list(DISPS) + [float(W) + 0.5, -float(H) - 1.25]                 # incl. |shift| >= size: the roll's identity clamp
+    S = len(disps)
+    tab_s, tab_w = shift_table(disps, views)
+    ts, tw = torch.from_numpy(tab_s).to(dev), torch.from_numpy(tab_w).to(dev)
+    outs = [torch.empty((S, views, 3, H, W), device=dev) for _ in range(4)]
+    call('mmlf_shift_views', *[ptr(t) for t in src], *[ptr(t) for t in outs], ptr(ts), ptr(tw), S, views, H, W, _lib.stream_ptr())
+    geo = engine.Geometry(S, H, W)
+    cs = engine.cs_of(views * 3)
+    for kind in range(4):
+        a, b = geo.buf(cs, dev), geo.buf(cs, dev)
+        a.fill_(7.0); b.fill_(-3.0)                                        # whatever was there: every grid element must be written
+        call('mmlf_zero_slack', ptr(a), cs, S, H, W, ptr(a.absmax), _lib.stream_ptr())
+        call('mmlf_zero_slack', ptr(b), cs, S, H, W, ptr(b.absmax), _lib.stream_ptr())
+        call('mmlf_pack_nchw', ptr(outs[kind]), views * 3, ptr(a), cs, S, H, W, ptr(a.absmax), _lib.stream_ptr())
+        call('mmlf_shift_pack', ptr(src[kind]), kind, ptr(b), cs, ptr(ts), ptr(tw), S, views, H, W, ptr(b.absmax), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), kind
+        assert torch.equal(geo.amax_canonical(a.absmax), geo.amax_canonical(b.absmax)), kind
+
+
+@pytest.mark.gpu
+def test_ensamble_hip_matches_reference(monkeypatch):
+    from mmlf_amd import ensamble
     g = load_golden('g4_ensamble.npz')
     dev = torch.device('cuda:0')
     ens = Ensamble(_model(g, dev), -3.5, 3.5, 0.1)
     ens.eval()
+    assert ensamble.FUSED_MEMBERS
     with torch.no_grad():
         out = ens(*[torch.from_numpy(g[f'in{i}']).to(dev) for i in range(4)])
     _check(out, g)
+    # the fused member path (shift straight into the grid layout, no member posterior) gives the bits of the module's own forward
+    monkeypatch.setattr(ensamble, 'FUSED_MEMBERS', False)
+    with torch.no_grad():
+        plain = ens(*[torch.from_numpy(g[f'in{i}']).to(dev) for i in range(4)])
+    for k in ('means', 'logvars', 'mean', 'logvar', 'posterior'):
+        assert torch.equal(out[k], plain[k]), k
+    monkeypatch.setattr(ensamble, 'FUSED_MEMBERS', True)
     # chunked members give the same result as one batch
     ens.member_budget_bytes = 1
     with torch.no_grad():
