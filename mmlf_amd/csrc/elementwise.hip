@@ -980,58 +980,82 @@ __global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ h,
 // KIND: 0 = horizontal stack (roll along W), 1 = vertical (along H), 2 = increasing diagonal (W, then H with the NEGATED
 // shift, hci4d.py:971-975), 3 = decreasing diagonal (W, then H).
 // ---------------------------------------------------------------------------------------------
+// the same index as roll_src for 0 <= x < n, without an integer division: |s| < n (else the identity), so x - s lies in (-n, 2n)
+__device__ __forceinline__ int roll_src_fast(int x, int s, int n)
+{
+    if (s >= n || -s >= n) return x;
+    int a = x - s;
+    a += a < 0 ? n : 0;
+    a -= a >= n ? n : 0;
+    return a;
+}
+struct ShiftPackTab { int s0, s1; float w0, w1; int ya, yb, pad0, pad1; };     // + the two source rows of this grid row
 template <int KIND>
 __global__ __launch_bounds__(256) void shift_pack_kernel(const float *__restrict__ src, int views, float *__restrict__ grid,
                                                          int cs, const int32_t *__restrict__ tab_s,
                                                          const float *__restrict__ tab_w, int H, int W,
-                                                         float *__restrict__ amax, int xt)
+                                                         float *__restrict__ amax, int xt_log)
 {
+    // No integer division in the loops (the first form, with pack_nchw_kernel's e / nx indexing and roll_src's two remainders per
+    // index, took 1.4-2.2 ms per stream of a 70-member 512 x 512 scene: as long as the two kernels it replaced): a thread keeps
+    // ONE position of the piece and walks the channels; a grid row's source rows are found once per view.
     extern __shared__ float tile[];            // [cs][xt | 1] channel-major, then the member's shift table
     const int P = W + MMLF_GRID_PAD_W, R = H + MMLF_GRID_PAD_H;
     const int C = views * 3;
+    const int xt = 1 << xt_log;
     const int row = blockIdx.x;                // (member s, grid row y)
     const int s = row / R, y = row - s * R;
     const size_t base = (size_t)row * P;
     const int c4n = cs / 4;
     const int pitch = xt | 1;
-    ShiftTab *tab = reinterpret_cast<ShiftTab *>(tile + (size_t)cs * pitch);      // [views]
-    for (int k = threadIdx.x; k < views; k += blockDim.x) {
-        tab[k].s0 = tab_s[2 * (s * views + k)]; tab[k].s1 = tab_s[2 * (s * views + k) + 1];
-        tab[k].w0 = tab_w[2 * (s * views + k)]; tab[k].w1 = tab_w[2 * (s * views + k) + 1];
-    }
-    __syncthreads();
     const bool row_in = (y >= 1 && y <= H);
     const int yi = y - 1;
+    ShiftPackTab *tab = reinterpret_cast<ShiftPackTab *>(tile + (size_t)cs * pitch);      // [views]
+    for (int k = threadIdx.x; k < views; k += blockDim.x) {
+        ShiftPackTab t;
+        t.s0 = tab_s[2 * (s * views + k)]; t.s1 = tab_s[2 * (s * views + k) + 1];
+        t.w0 = tab_w[2 * (s * views + k)]; t.w1 = tab_w[2 * (s * views + k) + 1];
+        const int sg = KIND == 2 ? -1 : 1;
+        t.ya = (KIND == 0 || !row_in) ? yi : roll_src_fast(yi, sg * t.s0, H);
+        t.yb = (KIND == 0 || !row_in) ? yi : roll_src_fast(yi, sg * t.s1, H);
+        t.pad0 = t.pad1 = 0;
+        tab[k] = t;
+    }
+    __syncthreads();
+    const int tl = threadIdx.x & (xt - 1), c_first = threadIdx.x >> xt_log, c_step = 256 >> xt_log;
+    const int dxl = 256 / c4n, dcg = 256 - dxl * c4n;          // the write-out's (position, channel group) stride, once
+    const size_t plane = (size_t)H * W;
     float mx = 0.f;
     for (int x0 = 0; x0 < P; x0 += xt) {
         const int nx = min(xt, P - x0);
-        for (int e = threadIdx.x; e < cs * nx; e += blockDim.x) {
-            const int c = e / nx, x = x0 + e - c * nx;         // x fastest: coalesced plane reads
+        const int x = x0 + tl, xi = x - 1;
+        const bool in_x = row_in && tl < nx && x >= 1 && x <= W;
+        int view = 0, ch = 0;                                   // c = 3 view + ch, stepped without a division
+        for (int k = 0; k < c_first; ++k) { if (++ch == 3) { ch = 0; ++view; } }
+        for (int c = c_first; c < cs; c += c_step) {
             float v = 0.f;
-            if (row_in && x >= 1 && x <= W && c < C) {
-                const int view = c / 3;
-                const ShiftTab t = tab[view];
-                const float *p = src + (size_t)c * H * W;       // plane (view, colour) = channel c
-                const int xi = x - 1;
+            if (in_x && c < C) {
+                const ShiftPackTab t = tab[view];
+                const float *p = src + (size_t)c * plane;       // plane (view, colour) = channel c
                 auto lerp = [&](float a, float b) { return __fadd_rn(__fmul_rn(a, t.w0), __fmul_rn(b, t.w1)); };
                 if (KIND == 0) {
-                    v = lerp(p[(size_t)yi * W + roll_src(xi, t.s0, W)], p[(size_t)yi * W + roll_src(xi, t.s1, W)]);
+                    v = lerp(p[(size_t)yi * W + roll_src_fast(xi, t.s0, W)], p[(size_t)yi * W + roll_src_fast(xi, t.s1, W)]);
                 } else if (KIND == 1) {
-                    v = lerp(p[(size_t)roll_src(yi, t.s0, H) * W + xi], p[(size_t)roll_src(yi, t.s1, H) * W + xi]);
+                    v = lerp(p[(size_t)t.ya * W + xi], p[(size_t)t.yb * W + xi]);
                 } else {
-                    const int sg = KIND == 2 ? -1 : 1;
-                    const int xa = roll_src(xi, t.s0, W), xb = roll_src(xi, t.s1, W);
-                    const int ya = roll_src(yi, sg * t.s0, H), yb = roll_src(yi, sg * t.s1, H);
-                    const float ta = lerp(p[(size_t)ya * W + xa], p[(size_t)ya * W + xb]);
-                    const float tb = lerp(p[(size_t)yb * W + xa], p[(size_t)yb * W + xb]);
+                    const int xa = roll_src_fast(xi, t.s0, W), xb = roll_src_fast(xi, t.s1, W);
+                    const float ta = lerp(p[(size_t)t.ya * W + xa], p[(size_t)t.ya * W + xb]);
+                    const float tb = lerp(p[(size_t)t.yb * W + xa], p[(size_t)t.yb * W + xb]);
                     v = lerp(ta, tb);
                 }
             }
-            tile[c * pitch + (x - x0)] = v;
+            if (tl < nx) tile[c * pitch + tl] = v;
+            for (int k = 0; k < c_step; ++k) { if (++ch == 3) { ch = 0; ++view; } }
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < nx * c4n; e += blockDim.x) {
-            const int xl = e / c4n, cg = e - xl * c4n;         // channel group fastest: coalesced grid writes
+        int xl = threadIdx.x / c4n, cg = threadIdx.x - xl * c4n;          // channel group fastest: coalesced grid writes
+        for (; xl < nx; xl += dxl, cg += dcg) {
+            if (cg >= c4n) { cg -= c4n; ++xl; if (xl >= nx) break; }
             const float4 o = make_float4(tile[(4 * cg) * pitch + xl], tile[(4 * cg + 1) * pitch + xl],
                                          tile[(4 * cg + 2) * pitch + xl], tile[(4 * cg + 3) * pitch + xl]);
             mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
@@ -1604,10 +1628,12 @@ extern "C" int mmlf_shift_pack(const float *in, int kind, float *grid, int cs, c
     MMLF_CHECK_ARG(kind >= 0 && kind <= 3, "mmlf_shift_pack: kind=%d", kind);
     MMLF_CHECK_ARG(S > 0 && views > 0 && H > 0 && W > 0 && cs % 4 == 0 && views * 3 <= cs, "mmlf_shift_pack: S=%d views=%d cs=%d",
                    S, views, cs);
-    int xt = PACK_XT;
-    while (xt > 4 && (size_t)cs * (xt | 1) * sizeof(float) > 32 * 1024) xt >>= 1;
-    const size_t lds = (size_t)cs * (xt | 1) * sizeof(float) + (size_t)views * sizeof(ShiftTab);
-    MMLF_CHECK_ARG(lds <= 64 * 1024, "mmlf_shift_pack: cs=%d does not fit the transpose tile", cs);
+    int xt = PACK_XT, xt_log = 7;                 // 128 positions per piece, halved until the tile fits 32 KB
+    static_assert(PACK_XT == 128, "xt_log");
+    while (xt > 4 && (size_t)cs * (xt | 1) * sizeof(float) > 32 * 1024) { xt >>= 1; --xt_log; }
+    const size_t lds = (size_t)cs * (xt | 1) * sizeof(float) + (size_t)views * sizeof(ShiftPackTab);
+    MMLF_CHECK_ARG(lds <= 64 * 1024 && cs / 4 <= 256, "mmlf_shift_pack: cs=%d does not fit the transpose tile", cs);
+    xt = xt_log;
     const dim3 g((unsigned)(S * (H + MMLF_GRID_PAD_H))), b(256);
     hipStream_t st = (hipStream_t)stream;
     switch (kind) {
