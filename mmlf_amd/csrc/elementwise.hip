@@ -1030,8 +1030,12 @@ __global__ __launch_bounds__(256) void shift_pack_kernel(const float *__restrict
         const int nx = min(xt, P - x0);
         const int x = x0 + tl, xi = x - 1;
         const bool in_x = row_in && tl < nx && x >= 1 && x <= W;
-        int view = 0, ch = 0;                                   // c = 3 view + ch, stepped without a division
-        for (int k = 0; k < c_first; ++k) { if (++ch == 3) { ch = 0; ++view; } }
+        // c = 3 view + ch, stepped without a division (c_step = 256 / xt channels per iteration: 2 at 128-position pieces).  The
+        // loop is unrolled so that several channels' source loads (L2 hits, 2-4 per sample, dependent on nothing but the index
+        // arithmetic) are in flight at once: one channel at a time the kernel was bound by their latency.
+        int view = c_first / 3, ch = c_first - 3 * view;        // (c_first < 256 / xt: a small constant divide, once per piece)
+        const int dv = c_step / 3, dc = c_step - 3 * dv;
+#pragma unroll 8
         for (int c = c_first; c < cs; c += c_step) {
             float v = 0.f;
             if (in_x && c < C) {
@@ -1050,7 +1054,8 @@ __global__ __launch_bounds__(256) void shift_pack_kernel(const float *__restrict
                 }
             }
             if (tl < nx) tile[c * pitch + tl] = v;
-            for (int k = 0; k < c_step; ++k) { if (++ch == 3) { ch = 0; ++view; } }
+            view += dv; ch += dc;
+            if (ch >= 3) { ch -= 3; ++view; }
         }
         __syncthreads();
         int xl = threadIdx.x / c4n, cg = threadIdx.x - xl * c4n;          // channel group fastest: coalesced grid writes
