@@ -179,7 +179,7 @@ class GradBuckets:
 class TrainStep:
     def __init__(self, model, lr, variant=None, warm_start=False, cooling=0, betas=(0.9, 0.999), eps=1e-8,
                  loss_margin=11, process_group=None, loss_multimodal=False, loss_padding=None,
-                 train_eval_mode=False, train_eval_mode_start=0, loss_strongest=False):
+                 train_eval_mode=False, train_eval_mode_start=0, loss_strongest=False, force_distributed=False):
         self.model = model
         # --train_eval_mode / --train_eval_mode_start (train/cli.py:227-230): BatchNorm uses its running statistics
         self.eval_mode, self.eval_mode_start = bool(train_eval_mode), int(train_eval_mode_start)
@@ -197,7 +197,10 @@ class TrainStep:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.adam_steps = 0
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        # force_distributed: take the data-parallel path (broadcasts, mask-count and bucket all-reduces) also in a process group
+        # of ONE rank -- the only way to put RCCL itself under this code on a one-GPU box (tests/test_gpu_ddp.py)
+        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(process_group) > 1
+                                                                              or bool(force_distributed))
         self.group = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self.buckets = GradBuckets(self.layout, process_group, self._agreed_bucket_count()) if self.distributed else None

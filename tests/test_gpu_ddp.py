@@ -143,6 +143,41 @@ def test_two_ranks_one_gpu_native_path(tmp_path, variant):
         torch.testing.assert_close(r0['flat'][cpu_solid], cpu_steps[0].flat[cpu_solid], rtol=1e-4, atol=cpu_atol)
 
 
+def _rccl_single_rank_worker(_rank, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from mmlf_amd.train import TrainStep
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))
+    try:
+        res = {}
+        stacks, gt, mask = _data()
+        for tag, force in (('plain', False), ('rccl', True)):
+            step = TrainStep(_make(3, 'dpp'), lr=1e-2, loss_margin=3, force_distributed=force)
+            assert step.distributed == force and (step.buckets is not None) == force
+            losses = [float(step(*stacks, gt, mask, it)) for it in (1, 2, 3)]
+            torch.cuda.synchronize()
+            res[tag] = {'flat': step.flat.cpu(), 'grad': step.grad.cpu(), 'losses': losses}
+        torch.save(res, os.path.join(out_dir, 'rccl.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_carries_the_gradient_in_a_group_of_one(tmp_path):
+    """RCCL itself under the data-parallel path (round 6): no multi-GPU box has ever been available to this build, so the
+    collective library's streams and the kernels this package launches through ctypes had never met.  A process group of ONE
+    rank on the `nccl` backend (= RCCL) with `force_distributed=True`: the weight / buffer broadcasts, the mask-count
+    all-reduce issued before forward and waited for before the loss kernel, the bucket all-reduces fired from the native
+    backward (async, on RCCL's stream) and waited for before Adam.  A one-rank sum changes no value, so three steps must
+    give the bits of the non-distributed step -- which they only do if every stream dependency is in place (a gradient read
+    before its kernels finished, or Adam running before a bucket's wait, would show).  Not a bandwidth measurement."""
+    mp.spawn(_rccl_single_rank_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(tmp_path / 'rccl.pt')
+    assert res['plain']['losses'] == res['rccl']['losses']
+    assert torch.equal(res['plain']['grad'], res['rccl']['grad'])
+    assert torch.equal(res['plain']['flat'], res['rccl']['flat'])
+    assert torch.isfinite(res['rccl']['flat']).all()
+
+
 def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     """bench.py's N>1 path end to end on the one GPU of this box: torch.distributed.run launcher, process-group
     init, sharded batch, bucketed all-reduce hooks fired from the native backward, max-over-ranks timing and rank 0's
