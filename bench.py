@@ -163,13 +163,31 @@ def timed_steps(step, data, steps, first_it, sync):
     return time.time() - t0, loss, 1e3 * host / max(1, steps)
 
 
+class stdout_to_stderr:
+    """RCCL prints a banner (version, HIP / ROCm version, hostname, library path) to STDOUT when its first communicator is made;
+    this script's contract is ONE JSON line there.  File-descriptor level, so that the library's own writes are caught."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+FORCE_DIST = False     # --rccl-self: the data-parallel path in a process group of ONE rank (RCCL's API and streams under the step)
+
+
 def make_step(variant, B, patch, dev, seed):
     from mmlf_amd.feed_forward import FeedForward
     from mmlf_amd.train import TrainStep
     kw = dict(BASE_KW, **KW_EXTRA[variant])
     torch.manual_seed(0)
     model = FeedForward(**kw).to(dev)
-    step = TrainStep(model, lr=1e-3, loss_margin=11)
+    step = TrainStep(model, lr=1e-3, loss_margin=11, force_distributed=FORCE_DIST)
     gen = torch.Generator(device=dev).manual_seed(seed)
     stacks = [torch.rand((B, 9, 3, patch, patch), device=dev, generator=gen) for _ in range(4)]
     gt = 4.0 * torch.rand((B, patch, patch), device=dev, generator=gen) - 2.0
@@ -309,6 +327,10 @@ def main():
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the extra exact-f32-MFMA measurement')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the UPR / DPP / shard-64 / ESE measurements')
     ap.add_argument('--ese-size', type=int, default=512, help='frame size of the ESE legs (BASELINE.json configs[4]: 512)')
+    ap.add_argument('--rccl-self', action='store_true',
+                    help='with --gpus 1: run the N > 1 code path of this script (process group on the nccl backend, distributed '
+                         'TrainStep, bucket waits, dpp / upr legs, ESE replica reductions) in a group of ONE rank -- a rehearsal of '
+                         'every torch.distributed call under RCCL on a one-GPU box; no link traffic, not a scaling measurement')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo: rehearsal of the N>1 path with every rank on whatever GPUs exist (one is enough)')
     args = ap.parse_args()
@@ -316,19 +338,27 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    global FORCE_DIST
+    FORCE_DIST = bool(args.rccl_self)
+    assert not FORCE_DIST or world == 1, '--rccl-self is the one-rank rehearsal'
+    dist_on = world > 1 or FORCE_DIST          # everything below that talks to torch.distributed
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     dev_index = local_rank % torch.cuda.device_count() if args.backend == 'gloo' else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
-        if args.backend == 'nccl':       # RCCL over xGMI
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+    if dist_on:
+        with stdout_to_stderr():         # (communicator set-up and its first collective: whatever the library prints goes to stderr)
+            if args.backend == 'nccl':       # RCCL over xGMI
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group('gloo', rank=rank, world_size=world)
+            dist.barrier()
+            torch.cuda.synchronize()
 
     from mmlf_amd import engine, _lib
 
@@ -337,7 +367,7 @@ def main():
     step, stacks, gt, mask = make_step(args.variant, B, args.patch, dev, seed=rank)
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -356,7 +386,7 @@ def main():
     # further legs (N=1 only): the same step in the two arithmetic modes that carry no precision asterisk -- the exact-f32
     # MFMA kernels (5 steps) and the exact 3 x bf16 split (3 steps) -- same tensors, same shapes
     mode_legs = {}
-    if world == 1 and not args.no_f32_leg:
+    if not dist_on and not args.no_f32_leg:
         for mode_name, nsteps in (('f32', 5), ('bf16x6', 3)):
             if engine.CONV_MODE == mode_name:
                 continue
@@ -385,7 +415,7 @@ def main():
                 'launches': len(p1), 'avg_ms': round(1e3 * s1 / max(1, len(p1)), 3)}
     tmax = torch.tensor([dt, host_ms], dtype=torch.float64, device=dev)
     tmin = tmax.clone()
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)       # a slow rank shows as max well above min
     dt, dt_min, host_ms = float(tmax[0]), float(tmin[0]), float(tmax[1])
@@ -393,12 +423,12 @@ def main():
 
     n_buckets = len(step.buckets.ranges) if step.buckets is not None else 0
     grad_bytes = int(step.grad.numel()) * 4
-    allreduce_ms, allreduce_by_bucket = allreduce_report(step, dev) if world > 1 else (None, None)
+    allreduce_ms, allreduce_by_bucket = allreduce_report(step, dev) if dist_on else (None, None)
     # BASELINE.json configs[4] under --gpus N: replicas only -- every rank runs its own 512x512 light field
     # through the 70-member Ensamble, no collective on the data path; reported as max-over-ranks seconds per scene
     ese_rep = None
     ddp_legs = {}
-    if world > 1 and not args.no_extra_legs:
+    if dist_on and not args.no_extra_legs:
         passes_ = {'f16x3': 3, 'bf16x6': 6}.get(engine.CONV_MODE)
         peak_ = PEAK_BF16_MFMA_TFLOPS / passes_ if passes_ else PEAK_F32_MFMA_TFLOPS
         del step, stacks, gt, mask
@@ -500,7 +530,7 @@ def main():
                 'launches': len(wprof), 'avg_ms': round(1e3 * wsecs / len(wprof), 3),
                 'avg_ms_main_stream': avg(main), 'avg_ms_side_stream': avg(side),
                 'algorithmic_bytes': walg, 'traffic_ratio': round(wtraffic[0] / walg, 3) if wtraffic[0] else None}
-        if world > 1:
+        if dist_on:
             line['ms_per_step_by_rank'] = {'min': round(1e3 * dt_min / args.steps, 3), 'max': round(1e3 * dt / args.steps, 3)}
             line['config']['buckets'] = n_buckets
             line['config']['buckets_env'] = os.environ.get('MMLF_GRAD_BUCKETS')
@@ -520,6 +550,9 @@ def main():
                 line[v] = leg
         if args.backend != 'nccl':
             line['config']['backend'] = args.backend + ' (rehearsal: not an xGMI measurement)'
+        if FORCE_DIST:
+            line['config']['backend'] = (args.backend + ', --rccl-self: the N > 1 code path in a process group of ONE rank (every '
+                                         'torch.distributed call of this script under the backend; no link traffic, not a scaling measurement)')
         if 'f32' in mode_legs:
             line['exact_f32_mfma_path'] = mode_legs['f32']
         if 'bf16x6' in mode_legs:
@@ -528,7 +561,7 @@ def main():
             line['strict_precision'] = dict({k: v['value'] for k, v in mode_legs.items()}, unit='patches/s',
                                             note='bf16x6 = exact 3 x bf16 operand split, f32 = exact-f32 MFMA; `value` above is the '
                                                  'f16x3 mode (22 significant bits per operand, float32-level error measured)')
-        if world == 1 and not args.no_extra_legs and args.global_batch == 512 and args.patch == 96:
+        if not dist_on and not args.no_extra_legs and args.global_batch == 512 and args.patch == 96:
             # the other BASELINE.json configs, driver-timed in the same run (single GPU each)
             del step, stacks, gt, mask
             torch.cuda.empty_cache()
@@ -546,7 +579,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.variant, args.patch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

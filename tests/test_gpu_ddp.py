@@ -211,3 +211,25 @@ def test_bench_two_ranks_gloo_rehearsal(tmp_path):
     rep = line['ese_replicas']
     assert rep['scenes'] == 2 and rep['members'] == 70 and rep['finite'] and rep['value'] > 0
     assert abs(rep['scenes_per_s'] - 2 / rep['value']) < 1e-2 * rep['scenes_per_s']
+
+
+def test_bench_rccl_self_rehearsal_prints_one_line():
+    """bench.py --rccl-self (round 6): every torch.distributed call of the script's N > 1 path -- process group on the nccl
+    backend (= RCCL), the distributed TrainStep, per-bucket waits, the dpp / upr legs, the ESE replica reductions -- in a group
+    of ONE rank on this box's GPU.  RCCL prints a version banner to stdout when its communicator is made: the script must
+    still put exactly ONE line there, the JSON line (the driver parses it)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--rccl-self', '--global-batch', '4', '--patch', '32',
+           '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--ese-size', '48']
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(out) == 1 and out[0].startswith('{'), res.stdout[-1500:]
+    line = json.loads(out[0])
+    assert 'rccl-self' in line['config']['backend'] and line['config']['buckets'] == 3
+    assert len(line['allreduce_ms_by_bucket']) == 3 and line['dpp']['value'] > 0 and line['upr']['value'] > 0
+    assert line['ese_replicas']['scenes'] == 1 and line['ese_replicas']['finite']
