@@ -22,10 +22,13 @@ for case in range(ncase):
     W = int(rs.choice([9, 14, 17, 29, 30, 31, 32, 33, 47, 64, 96, 125, 126, 127, 128, 130]))
     if B * H * W > 40000:
         B = 1
-    kw = dict(KW, model_uncert=variant == 'upr', model_discrete=variant == 'dpp')
+    # FUZZ_VIEWS=1 (round 6): the number of views per stack varies too -- 27 input channels is the README default, the reference
+    # takes any odd count (3 / 5 / 7 / 11 views = 9 / 15 / 21 / 33 input channels = 2 ... 5 chunks; the DPP head is 4 x views x 3 wide)
+    views = int(rs.choice([3, 5, 7, 9, 11])) if os.environ.get('FUZZ_VIEWS') else 9
+    kw = dict(KW, model_views=views, model_uncert=variant == 'upr', model_discrete=variant == 'dpp')
     state = synth.synth_state(synth.param_spec(**kw), 100 + case)
     g = torch.Generator().manual_seed(case)
-    stacks = [torch.rand((B, 9, 3, H, W), generator=g) for _ in range(4)]
+    stacks = [torch.rand((B, views, 3, H, W), generator=g) for _ in range(4)]
     gt = 4.0 * torch.rand((B, H, W), generator=g) - 2.0
     mask = (torch.rand((B, H, W), generator=g) > 0.2).int()
     res = {}
@@ -49,6 +52,6 @@ for case in range(ncase):
     berr = max(float((res['cuda'][3][n].double() - bb.double()).abs().max()) for n, bb in res['cpu'][3].items())
     worst = max(worst, gerr)
     flag = '' if (mae < 1e-4 and gerr < 5e-2 and berr < 1e-4 and abs(res['cpu'][1] - res['cuda'][1]) < 1e-4 * max(1, abs(res['cpu'][1]))) else '   <-- CHECK'
-    print(f'{case:3d} {variant} B={B} H={H} W={W}: depth MAE {mae:.2e}  loss {res["cpu"][1]:.6f} / {res["cuda"][1]:.6f}  '
+    print(f'{case:3d} {variant} views={views} B={B} H={H} W={W}: depth MAE {mae:.2e}  loss {res["cpu"][1]:.6f} / {res["cuda"][1]:.6f}  '
           f'worst grad rel {gerr:.2e}  buffers {berr:.1e}{flag}', flush=True)
 print('worst gradient relative error', worst)
