@@ -153,3 +153,26 @@ def test_validate_scene_hip():
     ref = float(((out['mean'][0, 3:-3, 3:-3]) ** 2).mean())
     np.testing.assert_allclose(float(mse), ref, rtol=1e-5)
     assert 0.0 <= float(bad) <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('views,b,H,W', [(7, 2, 20, 28), (11, 1, 31, 17), (3, 3, 16, 16)])
+def test_fused_members_equal_the_modules_own_forward_on_other_shapes(views, b, H, W, monkeypatch):
+    """the fused member path (mmlf_shift_pack + trunk on packed inputs) against mmlf_shift_views + the module's own forward for
+    other view counts, batches above one and non-square frames: the same bits in every output of the Ensamble"""
+    from mmlf_amd import ensamble, synth
+    kw = dict(TINY_KW, model_views=views, model_uncert=True)
+    m = FeedForward(**kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.synth_state(synth.param_spec(**kw), 5).items()})
+    dev = torch.device('cuda:0')
+    ens = Ensamble(m.to(dev).eval(), -3.5, 3.5, 0.5).eval()
+    g = torch.Generator().manual_seed(views)
+    stacks = [torch.rand((b, views, 3, H, W), generator=g).to(dev) for _ in range(4)]
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ensamble, 'FUSED_MEMBERS', fused)
+        with torch.no_grad():
+            res[fused] = {k: v.clone() for k, v in ens(*stacks).items()}
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), k
+    assert torch.isfinite(res[True]['mean']).all()
