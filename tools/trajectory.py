@@ -88,6 +88,12 @@ def main():
     lb, wb, _ = res['bf16x6']
     dl = max(abs(a - b) / max(abs(b), 1e-30) for a, b in zip(l, lb))
     print(f'{"f16x3 vs bf16x6":>22}: {summary(distances(w, wb))}   max relative loss difference {dl:.3e}')
+    # per tensor: relative L2 distance of the final weights from the f32 run's
+    cols = {tag: distances(res[tag][1], ref_w) for tag in ('f32/rolled', 'bf16x6', 'f16x3')}
+    cols['f16x3 vs bf16x6'] = distances(w, wb)
+    print(f'{"tensor":<34}' + ''.join(f'{t:>18}' for t in cols))
+    for k in cols['f16x3']:
+        print(f'{k:<34}' + ''.join(f'{cols[t].get(k, float("nan")):18.3e}' for t in cols))
     print('trajectory ok' if all(np.isfinite(res[t][0]).all() for t in res) else 'NaN')
 
 
